@@ -1,0 +1,199 @@
+/*
+ * mcamd.h — C ABI of the MI355X (gfx950) Monte Carlo option-pricing engine.
+ *
+ * This is the drop-in boundary for the hot path of amauryrlm/Monte-Carlo-Project-CUDA.
+ * The reference has no FFI: its "API" is the header-level C++ surface of inc/wrappers.cuh,
+ * inc/tool.cuh, inc/testing.cuh and inc/BlackandScholes.hpp called from hello.cu / testing.cu.
+ * Each entry point below names the reference interface (file:line under the reference root)
+ * it replaces; include/wrappers.hpp and friends re-expose the reference's own names on top of
+ * this ABI.  Plain C types only: pointers, sizes, POD structs, int status codes.
+ *
+ * Conventions
+ *  - every function returns MCAMD_OK (0) or an MCAMD_ERR_* code and never calls exit()
+ *    (the reference's testCUDA / CHECK_MALLOC exit the process: inc/tool.cuh:47-53,92-100);
+ *    mcamd_last_error() returns the calling thread's last message;
+ *  - "d_" pointers are device (HBM) pointers on the context's device, owned by the caller;
+ *  - calls are synchronous on the context's stream (as the reference's wrappers are:
+ *    cudaDeviceSynchronize at inc/wrappers.cuh:48,79,115,157,233,297); a context is not
+ *    thread-safe, distinct contexts are independent;
+ *  - option parameters travel in the structs passed to each call; there is no global
+ *    __constant__ symbol to upload first (reference: hello.cu:22, inc/trajectories.cuh:12);
+ *  - random numbers: counter-based Philox4x32-10 held in registers, key = seed,
+ *    subsequence = GLOBAL path id, i.e. exactly rocrand_init(seed, path_id, 0) followed by
+ *    rocrand_normal4 (fp32, 4 steps per block) / rocrand_normal_double2 (fp64, 2 steps per
+ *    block).  There is no RNG state array and no setup kernel (replaces setup_kernel,
+ *    inc/tool.cuh:192-195, and init_rng_kernel, inc/testing.cuh:95-98).  Results therefore
+ *    do not depend on how paths are sharded over GPUs, blocks or threads;
+ *  - payoff sums are accumulated in fp64 whatever the path precision.
+ */
+#ifndef MCAMD_H
+#define MCAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCAMD_ABI_VERSION 1
+
+/* status codes */
+#define MCAMD_OK 0
+#define MCAMD_ERR_INVALID 1   /* bad argument (null pointer, zero steps, shape mismatch ...) */
+#define MCAMD_ERR_HIP 2       /* a HIP runtime call or kernel launch failed */
+#define MCAMD_ERR_NODEVICE 3  /* no usable gfx950 device */
+#define MCAMD_ERR_NOMEM 4     /* device or host allocation failed */
+
+/* arithmetic type of the simulated paths */
+#define MCAMD_F32 32
+#define MCAMD_F64 64
+
+/* trajectory / point-array layouts */
+#define MCAMD_STEP_MAJOR 0 /* a[step * n_paths_local + path]  — coalesced, the engine's native layout */
+#define MCAMD_PATH_MAJOR 1 /* a[path * n_steps + step]        — the reference's layout
+                              (inc/trajectories.cuh:304-305, inc/testing.cuh:69) */
+
+/* nested-MC inner strategies; all three give the same per-point prices */
+#define MCAMD_NMC_WAVE_PER_POINT 0  /* replaces compute_nmc_optimal, inc/nmc.cuh:280-386 */
+#define MCAMD_NMC_BLOCK_PER_POINT 1 /* replaces compute_nmc_one_block_per_point, inc/nmc.cuh:12-108 */
+
+/* reduce variants: names follow the reference's ReductionType (inc/testing.cuh:100-106) */
+#define MCAMD_REDUCE_SEQUENTIAL 3
+#define MCAMD_REDUCE_FIRST_ADD 4
+#define MCAMD_REDUCE_UNROLL_LAST 5
+#define MCAMD_REDUCE_GRID_STRIDE 6
+
+typedef struct mcamd_ctx mcamd_ctx;
+
+/* Option parameters: the reference's OptionData (inc/tool.cuh:13-26) in double precision,
+ * plus the restart triple the bullet kernels accept (inc/trajectories.cuh:116-117,140-143). */
+typedef struct mcamd_option {
+    double S0;          /* spot */
+    double T;           /* maturity */
+    double K;           /* strike */
+    double r;           /* risk-free rate */
+    double v;           /* volatility */
+    double B;           /* barrier level (bullet option) */
+    int32_t P1, P2;     /* payoff only if P1 <= #steps{B > St} <= P2 */
+    int32_t use_window; /* 0: European call (no barrier test at all); 1: bullet window */
+    int32_t Ik;         /* restart: initial barrier count */
+    double Sk;          /* restart: initial price; 0 means S0 (inc/trajectories.cuh:141) */
+    int32_t Tk;         /* restart: steps already elapsed; n_steps - Tk are simulated */
+    int32_t reserved;
+} mcamd_option;
+
+/* Simulation shape. The job has n_paths paths; this call simulates the shard
+ * [path_offset, path_offset + n_paths_local) of it.  A single-GPU caller passes
+ * path_offset = 0, n_paths_local = n_paths.  n_paths_local == 0 is a legal empty shard
+ * (all-zero statistics, nothing launched). */
+typedef struct mcamd_sim {
+    uint64_t n_paths;
+    uint64_t path_offset;
+    uint64_t n_paths_local;
+    uint32_t n_steps;       /* N_STEPS; dt = T / n_steps; 1 = the exact one-step pricer */
+    uint32_t n_paths_inner; /* N_PATHS_INNER (nested MC only) */
+    uint64_t seed;          /* the reference hard-codes 1234 / 1235 (inc/wrappers.cuh:41,163) */
+    int32_t precision;      /* MCAMD_F32 or MCAMD_F64 */
+    int32_t flags;          /* reserved, 0 */
+} mcamd_sim;
+
+/* Result of a pricing call. sum/sumsq/n are the shard's raw fp64 statistics (what a multi-GPU
+ * caller all-reduces); price..ci_hi are finalized from them as if the shard were the whole job
+ * (see mcamd_finalize). */
+typedef struct mcamd_result {
+    double sum;        /* sum of undiscounted payoffs */
+    double sumsq;      /* sum of squared undiscounted payoffs */
+    uint64_t n;        /* paths in the shard */
+    double price;      /* exp(-rT) * sum / n              (inc/wrappers.cuh:51,85,118) */
+    double std_err;    /* exp(-rT) * sqrt(s^2 / n)        (new: the reference has no variance) */
+    double ci_lo;      /* price -/+ 1.96 std_err */
+    double ci_hi;
+    float kernel_ms;   /* HIP-event time of the simulation kernel alone, on the context's stream */
+    float total_ms;    /* HIP-event time of the whole call's device work (kernel + final reduce + D2H) */
+    uint32_t grid;     /* launch shape the engine chose (threadsPerBlock / number_of_blocks of the */
+    uint32_t block;    /* reference wrappers are accepted by the shim and ignored) */
+} mcamd_result;
+
+/* Device report: replaces getDeviceProperty (inc/tool.cuh:56-88) and the free/total memory
+ * print of get_max_blocks (inc/tool.cuh:176-188). */
+typedef struct mcamd_device_info {
+    char name[256];
+    char arch[64];
+    uint64_t total_mem, free_mem;
+    int32_t compute_units, wavefront_size, max_threads_per_block, clock_khz, mem_clock_khz, mem_bus_bits;
+    int32_t lds_per_block, regs_per_block, l2_bytes, device_index, device_count, reserved;
+} mcamd_device_info;
+
+int mcamd_abi_version(void);
+const char *mcamd_last_error(void);
+int mcamd_device_count(int *count);
+
+/* hip_stream: a hipStream_t to launch on (e.g. the caller framework's current stream), or NULL
+ * to let the context create its own.  Scratch buffers are owned by the context and reused. */
+int mcamd_ctx_create(int device, void *hip_stream, mcamd_ctx **ctx);
+int mcamd_ctx_destroy(mcamd_ctx *ctx);
+int mcamd_get_device_info(mcamd_ctx *ctx, mcamd_device_info *info);
+
+/* In-register Monte Carlo: RNG -> GBM steps -> payoff -> fp64 (sum, sumsq); nothing is stored.
+ * Replaces the kernel + host tail of
+ *   wrapper_gpu_option_vanilla          inc/wrappers.cuh:33-57   (n_steps = 1)
+ *     simulateOptionPriceMultipleBlockGPUwithReduce  inc/trajectories.cuh:54-113
+ *   wrapper_gpu_bullet_option[_atomic]  inc/wrappers.cuh:59-125  (use_window = 1)
+ *     simulateBulletOptionPriceMultipleBlockGPU[atomic]  inc/trajectories.cuh:115-271
+ * and is the multi-step European pricer of BASELINE configs 2 and 5 (use_window = 0). */
+int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, mcamd_result *res);
+
+/* Trajectory store: as above, and every St (and, if d_counts != NULL, every running barrier
+ * count) is written to HBM.  d_traj: n_sim_steps * n_paths_local elements of the path precision
+ * (n_sim_steps = n_steps - Tk); d_counts: same shape, int32, or NULL; d_payoffs: n_paths_local
+ * undiscounted payoffs of the path precision, or NULL.
+ * Replaces simulateOptionPriceMultipleBlockGPU (trajectory overload) inc/testing.cuh:46-73 and
+ * simulate_outer_trajectories inc/trajectories.cuh:273-351. */
+int mcamd_simulate_trajectories(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout,
+                                void *d_traj, int32_t *d_counts, void *d_payoffs, mcamd_result *res);
+
+/* Array-driven pricer: normals are an input, d_normals[path * n_steps + step] (the reference's
+ * layout), precision per sim->precision; d_payoffs (nullable): n_paths_local payoffs.
+ * Replaces simulateOptionPriceGPU / simulateOptionPriceMultipleBlockGPU (array overloads)
+ * inc/trajectories.cuh:14-52; CPU twin inc/testing.cuh:75-91. */
+int mcamd_price_from_normals(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, const void *d_normals,
+                             void *d_payoffs, mcamd_result *res);
+
+/* Bulk N(0,1) fill of d_out[0..n): one Philox sequence (subsequence 0) consumed front to back,
+ * 4 floats / 2 doubles per block.  Replaces generate_random_array's curandGenerateNormal,
+ * inc/testing.cuh:17-24. */
+int mcamd_generate_normals(mcamd_ctx *ctx, uint64_t seed, uint64_t n, int precision, void *d_out, float *kernel_ms);
+
+/* Sum of d_in[0..n) (fp32 or fp64 elements) accumulated in fp64.  variant selects the schedule
+ * named after the reference's reduce3..reduce6 (inc/reduce.cuh:9-227); *sum is the complete sum
+ * for every variant (the reference leaves a per-block array for the caller to finish,
+ * inc/testing.cuh:227-234). */
+int mcamd_reduce_sum(mcamd_ctx *ctx, const void *d_in, uint64_t n, int precision, int variant, double *sum,
+                     float *kernel_ms);
+
+/* Nested Monte Carlo, inner stage: for every stored point (step, path) of the shard, n_paths_inner
+ * continuation paths of n_steps - 1 - step steps from (d_prices, d_counts), windowed payoff, mean,
+ * discount exp(-rT).  d_prices / d_counts are what mcamd_simulate_trajectories wrote (same layout
+ * argument); d_point_prices receives one value of the path precision per point in that layout.
+ * Inner stream: seed = sim->seed, subsequence = global_point_id * n_paths_inner + j with
+ * global_point_id = global_path * n_steps + step.
+ * Replaces compute_nmc_one_block_per_point / compute_nmc_optimal, inc/nmc.cuh:12-108,280-386.
+ * res->sum / n: sum and count of the per-point prices (the wrappers' scalar diagnostic,
+ * inc/wrappers.cuh:185-189,316-321). */
+int mcamd_nmc_inner(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout, int variant,
+                    const void *d_prices, const int32_t *d_counts, void *d_point_prices, mcamd_result *res);
+
+/* Host: discount + mean + standard error + 95% CI from (sum, sumsq, n) — after an all-reduce
+ * over shards, or directly.  Fills price/std_err/ci_* (and copies sum/sumsq/n) in *res. */
+int mcamd_finalize(double sum, double sumsq, uint64_t n, double r, double T, mcamd_result *res);
+
+/* Host closed form.  _f32 restates the reference's fp32 code path operation for operation
+ * (CND: inc/BlackandScholes.hpp:8-30; black_scholes_CPU: :34-43); _f64 is the exact erfc form. */
+float mcamd_cnd_f32(float x);
+float mcamd_bs_call_f32(float x0, float strike, float T, float r, float sigma);
+double mcamd_bs_call_f64(double x0, double strike, double T, double r, double sigma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCAMD_H */

@@ -1,0 +1,65 @@
+"""Builds libmcamd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so travels to the
+GPU box with the repository snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(PKG, "libmcamd.so")
+SOURCES = ["price.hip", "store.hip", "aux.hip", "nmc.hip", "capi.cpp"]
+HEADERS = ["launch.hpp", "mc_device.hpp", "path_consts.hpp"]
+ARCH = "gfx950"
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the engine is HIP-only and cannot be built without ROCm")
+    return exe
+
+
+def _flags(extra=()):
+    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *extra]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src: str, force: bool, extra) -> str:
+    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [
+        os.path.join(ROOT, "include", "mcamd.h"), os.path.abspath(__file__)]
+    if force or _stale(obj, deps):
+        cmd = [hipcc(), *_flags(extra), "-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".cpp"):
+            cmd[1:1] = ["-x", "hip", "-ffp-contract=off"]
+        subprocess.check_call(cmd)
+    return obj
+
+
+def build(force: bool = False, extra_flags=(), jobs: int = 4) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, tuple(extra_flags)), SOURCES))
+    if force or _stale(LIB, objs):
+        subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,257 @@
+// aux.hip — the kernels beside the two pricing paths: array-driven pricer, bulk normal fill,
+// stand-alone sum reductions.  gfx950 only.
+#include "path_consts.hpp"
+
+#include "mcamd.h"
+
+namespace mcamd {
+
+// ---------------------------------------------------------------------------------------------
+// Array-driven European pricer: normals are an input, d_normals[path * n_steps + step] (the
+// reference's layout).  Replaces simulateOptionPriceGPU / simulateOptionPriceMultipleBlockGPU
+// (array overloads), inc/trajectories.cuh:14-52; this is the deterministic parity path (its CPU
+// twin is inc/testing.cuh:75-91).  A wavefront stages a 64-path x 128-byte tile through LDS:
+// global reads are row-contiguous (one full 128 B line per path row), LDS reads are column-wise
+// (lane = path) with a +1 pad so the lanes of a group hit different banks.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct ArrayArgs {
+    StepConsts<T> c;
+    uint64_t n_local;
+    const T *normals;
+    T *payoffs;
+};
+
+template <typename T, bool WINDOW>
+__global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, double *__restrict__ partials)
+{
+    constexpr int kWaves = kBlock / kWave;
+    constexpr int TS = 128 / sizeof(T);        // tile width in steps: one 128 B line per path row
+    constexpr int kRowsPerLoad = kWave / TS;   // path rows one wave-wide load covers
+    __shared__ T tile[kWaves][kWave][TS + 1];
+    const StepConsts<T> &c = a.c;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int lcol = lane % TS, lrow = lane / TS;
+    const uint64_t n_tiles = (a.n_local + kWave - 1) / kWave;  // one tile row = 64 paths
+    const uint64_t wave_stride = static_cast<uint64_t>(gridDim.x) * kWaves;
+    double s = 0.0, s2 = 0.0;
+
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * kWaves + wave; t < n_tiles; t += wave_stride) {
+        const uint64_t path0 = t * kWave;
+        const uint64_t my_path = path0 + lane;
+        T St = c.S_start;
+        int32_t count = c.Ik;
+        for (uint32_t s0 = 0; s0 < c.n_sim; s0 += TS) {
+            const uint32_t n_cols = (c.n_sim - s0 < static_cast<uint32_t>(TS)) ? c.n_sim - s0 : TS;
+            // stage: global reads are contiguous along a path's row, LDS holds [path][step]
+            for (int r = 0; r < kWave; r += kRowsPerLoad) {
+                const uint64_t p = path0 + r + lrow;
+                if (p < a.n_local && static_cast<uint32_t>(lcol) < n_cols)
+                    tile[wave][r + lrow][lcol] = a.normals[p * c.n_sim + s0 + lcol];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (my_path < a.n_local) {
+                for (uint32_t j = 0; j < n_cols; ++j) {
+                    St = gbm_step(St, tile[wave][lane][j], c);
+                    if (WINDOW) count += (c.B > St) ? 1 : 0;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (my_path < a.n_local) {
+            const T pay = payoff<T, WINDOW>(St, count, c);
+            if (a.payoffs) a.payoffs[my_path] = pay;
+            const double pd = static_cast<double>(pay);
+            s += pd;
+            s2 = __builtin_fma(pd, pd, s2);
+        }
+    }
+    block_sum2<kBlock>(s, s2);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = s;
+        partials[2 * blockIdx.x + 1] = s2;
+    }
+}
+
+uint32_t array_grid(uint64_t n_local)
+{
+    return clamp_grid((n_local + kBlock - 1) / kBlock);
+}
+
+template <typename T>
+static hipError_t launch_from_normals_t(const PathJob &j, const void *d_normals, void *d_payoffs, double *d_partials,
+                                        uint32_t grid, hipStream_t stream)
+{
+    ArrayArgs<T> a{make_consts<T>(j), j.n_local, static_cast<const T *>(d_normals), static_cast<T *>(d_payoffs)};
+    if (j.window)
+        hipLaunchKernelGGL((from_normals_kernel<T, true>), dim3(grid), dim3(kBlock), 0, stream, a, d_partials);
+    else
+        hipLaunchKernelGGL((from_normals_kernel<T, false>), dim3(grid), dim3(kBlock), 0, stream, a, d_partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_from_normals(const PathJob &j, const void *d_normals, void *d_payoffs, double *d_partials,
+                               uint32_t grid, hipStream_t stream)
+{
+    return j.precision == 32 ? launch_from_normals_t<float>(j, d_normals, d_payoffs, d_partials, grid, stream)
+                             : launch_from_normals_t<double>(j, d_normals, d_payoffs, d_partials, grid, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bulk normal fill: out[NB k .. NB k + NB) = normals of Philox block k of subsequence 0.
+// Replaces curandGenerateNormal (inc/testing.cuh:17-24).  One 16 B store per lane per block:
+// pure HBM-write-bound, 4 B (fp32) / 8 B (fp64) per element, no reads.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void normals_kernel(uint64_t seed, uint64_t n, T *__restrict__ out, bool vec_ok)
+{
+    constexpr int NB = Normals<T>::kPerBlock;
+    const uint64_t n_blocks = (n + NB - 1) / NB;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; k < n_blocks; k += stride) {
+        Normals<T> nrm;
+        nrm.fill(seed, 0, k);
+        const uint64_t base = k * NB;
+        if (vec_ok && base + NB <= n) {
+            using VT = T __attribute__((ext_vector_type(NB)));
+            VT pack;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) pack[j] = nrm.z[j];
+            __builtin_nontemporal_store(pack, reinterpret_cast<VT *>(out + base));
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (base + j < n) out[base + j] = nrm.z[j];
+        }
+    }
+}
+
+hipError_t launch_generate_normals(uint64_t seed, uint64_t n, int precision, void *d_out, hipStream_t stream)
+{
+    const uint64_t nb = precision == 32 ? 4 : 2;
+    const uint32_t grid = clamp_grid(((n + nb - 1) / nb + kBlock - 1) / kBlock);
+    const bool vec_ok = reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
+    if (precision == 32)
+        hipLaunchKernelGGL(normals_kernel<float>, dim3(grid), dim3(kBlock), 0, stream, seed, n,
+                           static_cast<float *>(d_out), vec_ok);
+    else
+        hipLaunchKernelGGL(normals_kernel<double>, dim3(grid), dim3(kBlock), 0, stream, seed, n,
+                           static_cast<double *>(d_out), vec_ok);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone sum reductions.  The reference keeps four teaching variants of the NVIDIA SDK
+// reduction (inc/reduce.cuh:9-227: reduce3 sequential addressing + first add on load, reduce4
+// shuffle for the last warp, reduce5 fully unrolled, reduce6 grid-stride multi-element) and
+// lets the caller pick one (ReductionType, inc/testing.cuh:100-106).  The same choice is offered
+// here, re-thought for wave64; every variant accumulates in fp64 and leaves one partial per
+// block, finished by final_reduce_kernel:
+//   3  LDS tree with sequential addressing down to one element (barrier per level)
+//   4  LDS tree down to one wave, then wave64 shuffles
+//   5  wave64 shuffles first, one LDS slot per wave, first wave finishes (no tree at all)
+//   6  grid-stride, 16 B loads per lane, then as 5 — the production reduce
+// Variants 3-5 consume 2 elements per thread (first add on load), so their grid grows with n.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ double load2(const T *__restrict__ in, uint64_t n, uint64_t i)
+{
+    double v = i < n ? static_cast<double>(in[i]) : 0.0;
+    if (i + kBlock < n) v += static_cast<double>(in[i + kBlock]);
+    return v;
+}
+
+template <typename T, int VARIANT>
+__global__ __launch_bounds__(kBlock) void reduce_kernel(const T *__restrict__ in, uint64_t n,
+                                                        double *__restrict__ partials)
+{
+    __shared__ double sdata[kBlock];
+    const int tid = threadIdx.x;
+    double v = 0.0, zero = 0.0;
+    if (VARIANT == MCAMD_REDUCE_GRID_STRIDE) {
+        constexpr int V = 16 / sizeof(T);
+        using VT = T __attribute__((ext_vector_type(V)));
+        const uint64_t n_vec = (reinterpret_cast<uintptr_t>(in) % 16 == 0) ? n / V : 0;
+        const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+        const uint64_t gtid = static_cast<uint64_t>(blockIdx.x) * kBlock + tid;
+        const VT *vin = reinterpret_cast<const VT *>(in);
+        for (uint64_t i = gtid; i < n_vec; i += stride) {
+            const VT x = vin[i];
+#pragma unroll
+            for (int j = 0; j < V; ++j) v += static_cast<double>(x[j]);
+        }
+        for (uint64_t i = n_vec * V + gtid; i < n; i += stride) v += static_cast<double>(in[i]);
+        block_sum2<kBlock>(v, zero);
+    } else {
+        v = load2(in, n, static_cast<uint64_t>(blockIdx.x) * (2 * kBlock) + tid);
+        if (VARIANT == MCAMD_REDUCE_SEQUENTIAL) {
+            sdata[tid] = v;
+            __syncthreads();
+            for (int sft = kBlock / 2; sft > 0; sft >>= 1) {
+                if (tid < sft) sdata[tid] = v = v + sdata[tid + sft];
+                __syncthreads();
+            }
+        } else if (VARIANT == MCAMD_REDUCE_FIRST_ADD) {
+            sdata[tid] = v;
+            __syncthreads();
+            for (int sft = kBlock / 2; sft >= kWave; sft >>= 1) {
+                if (tid < sft) sdata[tid] = v = v + sdata[tid + sft];
+                __syncthreads();
+            }
+            if (tid < kWave) v = wave_sum(v);
+        } else {
+            block_sum2<kBlock>(v, zero);
+        }
+    }
+    if (tid == 0) {
+        partials[2 * blockIdx.x] = v;
+        partials[2 * blockIdx.x + 1] = 0.0;
+    }
+}
+
+uint32_t reduce_grid(uint64_t n, int variant)
+{
+    if (variant == MCAMD_REDUCE_GRID_STRIDE) {
+        // memory-bound: 256 CUs x 8 blocks, grid-stride the rest
+        const uint64_t want = (n + kBlock * 4 - 1) / (kBlock * 4);
+        return static_cast<uint32_t>(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    }
+    return clamp_grid((n + 2 * kBlock - 1) / (2 * kBlock));
+}
+
+template <typename T>
+static hipError_t launch_reduce_t(const void *d_in, uint64_t n, int variant, double *d_partials, uint32_t grid,
+                                  hipStream_t stream)
+{
+    const T *in = static_cast<const T *>(d_in);
+    const dim3 g(grid), b(kBlock);
+    switch (variant) {
+        case MCAMD_REDUCE_SEQUENTIAL:
+            hipLaunchKernelGGL((reduce_kernel<T, MCAMD_REDUCE_SEQUENTIAL>), g, b, 0, stream, in, n, d_partials);
+            break;
+        case MCAMD_REDUCE_FIRST_ADD:
+            hipLaunchKernelGGL((reduce_kernel<T, MCAMD_REDUCE_FIRST_ADD>), g, b, 0, stream, in, n, d_partials);
+            break;
+        case MCAMD_REDUCE_UNROLL_LAST:
+            hipLaunchKernelGGL((reduce_kernel<T, MCAMD_REDUCE_UNROLL_LAST>), g, b, 0, stream, in, n, d_partials);
+            break;
+        default:
+            hipLaunchKernelGGL((reduce_kernel<T, MCAMD_REDUCE_GRID_STRIDE>), g, b, 0, stream, in, n, d_partials);
+            break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce(const void *d_in, uint64_t n, int precision, int variant, double *d_partials, uint32_t grid,
+                         hipStream_t stream)
+{
+    return precision == 32 ? launch_reduce_t<float>(d_in, n, variant, d_partials, grid, stream)
+                           : launch_reduce_t<double>(d_in, n, variant, d_partials, grid, stream);
+}
+
+}  // namespace mcamd

@@ -1,0 +1,446 @@
+// capi.cpp — the C ABI declared in include/mcamd.h: argument checking, context/scratch
+// ownership, HIP-event timing, final host-side statistics.  All device work is enqueued through
+// the launchers of launch.hpp on the context's stream; there is no CPU fallback of any kind — a
+// call either runs the gfx950 kernels or returns an error.
+#include "launch.hpp"
+
+#include "mcamd.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            (void)hipGetLastError();                                                                   \
+            return fail(e_ == hipErrorOutOfMemory ? MCAMD_ERR_NOMEM : MCAMD_ERR_HIP, "%s: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                             \
+        }                                                                                              \
+    } while (0)
+
+}  // namespace
+
+struct mcamd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    double *d_partials = nullptr;  // 2 doubles per block
+    uint32_t partial_capacity = 0; // in pairs
+    double *d_out = nullptr;       // 2 doubles
+    double *h_out = nullptr;       // pinned, 2 doubles
+};
+
+namespace {
+
+int ensure_partials(mcamd_ctx *ctx, uint32_t pairs)
+{
+    if (pairs <= ctx->partial_capacity) return MCAMD_OK;
+    if (ctx->d_partials) HIP_TRY(hipFree(ctx->d_partials));
+    ctx->d_partials = nullptr;
+    ctx->partial_capacity = 0;
+    HIP_TRY(hipMalloc(&ctx->d_partials, static_cast<size_t>(pairs) * 2 * sizeof(double)));
+    ctx->partial_capacity = pairs;
+    return MCAMD_OK;
+}
+
+int check_common(const mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, const mcamd_result *res)
+{
+    if (!ctx) return fail(MCAMD_ERR_INVALID, "ctx is NULL");
+    if (!opt || !sim || !res) return fail(MCAMD_ERR_INVALID, "opt, sim and res must be non-NULL");
+    if (sim->precision != MCAMD_F32 && sim->precision != MCAMD_F64)
+        return fail(MCAMD_ERR_INVALID, "precision must be MCAMD_F32 (32) or MCAMD_F64 (64), got %d", sim->precision);
+    if (sim->n_steps == 0) return fail(MCAMD_ERR_INVALID, "n_steps must be >= 1");
+    if (opt->Tk < 0 || static_cast<uint32_t>(opt->Tk) >= sim->n_steps)
+        return fail(MCAMD_ERR_INVALID, "restart Tk=%d must satisfy 0 <= Tk < n_steps=%u", opt->Tk, sim->n_steps);
+    if (!(opt->T > 0.0) || !(opt->v >= 0.0) || !std::isfinite(opt->S0) || !std::isfinite(opt->K) ||
+        !std::isfinite(opt->r) || !std::isfinite(opt->T) || !std::isfinite(opt->v))
+        return fail(MCAMD_ERR_INVALID, "option parameters must be finite with T > 0 and v >= 0");
+    if (sim->path_offset + sim->n_paths_local < sim->path_offset)
+        return fail(MCAMD_ERR_INVALID, "path_offset + n_paths_local overflows 64 bits");
+    return MCAMD_OK;
+}
+
+mcamd::PathJob make_job(const mcamd_option *opt, const mcamd_sim *sim)
+{
+    mcamd::PathJob j;
+    const double dt = opt->T / static_cast<double>(sim->n_steps);
+    j.drift = (opt->r - 0.5 * opt->v * opt->v) * dt;
+    j.vol = opt->v * std::sqrt(dt);
+    j.K = opt->K;
+    j.B = opt->B;
+    j.S_start = (opt->Sk == 0.0) ? opt->S0 : opt->Sk;
+    j.P1 = opt->P1;
+    j.P2 = opt->P2;
+    j.Ik = opt->Ik;
+    j.n_sim = sim->n_steps - static_cast<uint32_t>(opt->Tk);
+    j.n_steps = sim->n_steps;
+    j.seed = sim->seed;
+    j.path_offset = sim->path_offset;
+    j.n_local = sim->n_paths_local;
+    j.window = opt->use_window != 0;
+    j.precision = sim->precision;
+    return j;
+}
+
+void zero_result(mcamd_result *res)
+{
+    std::memset(res, 0, sizeof *res);
+}
+
+// final reduce of `pairs` block partials -> host, with event timing; fills sum/sumsq + timings
+int finish(mcamd_ctx *ctx, uint32_t pairs, mcamd_result *res)
+{
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(mcamd::launch_final_reduce(ctx->d_partials, pairs, ctx->d_out, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev2, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipEventElapsedTime(&res->kernel_ms, ctx->ev0, ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(&res->total_ms, ctx->ev0, ctx->ev2));
+    res->sum = ctx->h_out[0];
+    res->sumsq = ctx->h_out[1];
+    return MCAMD_OK;
+}
+
+void finalize_into(double sum, double sumsq, uint64_t n, double r, double T, mcamd_result *res)
+{
+    const double disc = std::exp(-r * T);
+    const double N = static_cast<double>(n);
+    const double mean = n ? sum / N : 0.0;
+    double var = n > 1 ? (sumsq - N * mean * mean) / (N - 1.0) : 0.0;
+    if (var < 0.0) var = 0.0;
+    const double se = n ? disc * std::sqrt(var / N) : 0.0;
+    res->sum = sum;
+    res->sumsq = sumsq;
+    res->n = n;
+    res->price = disc * mean;
+    res->std_err = se;
+    res->ci_lo = res->price - 1.959963984540054 * se;
+    res->ci_hi = res->price + 1.959963984540054 * se;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcamd_abi_version(void)
+{
+    return MCAMD_ABI_VERSION;
+}
+
+const char *mcamd_last_error(void)
+{
+    return g_last_error.c_str();
+}
+
+int mcamd_device_count(int *count)
+{
+    if (!count) return fail(MCAMD_ERR_INVALID, "count is NULL");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *count = 0;
+        return fail(MCAMD_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    return MCAMD_OK;
+}
+
+int mcamd_ctx_create(int device, void *hip_stream, mcamd_ctx **out)
+{
+    if (!out) return fail(MCAMD_ERR_INVALID, "ctx out-pointer is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        return fail(MCAMD_ERR_NODEVICE, "no HIP device visible: this engine has no CPU fallback");
+    }
+    if (device < 0 || device >= count) return fail(MCAMD_ERR_INVALID, "device %d out of range [0, %d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MCAMD_ERR_NODEVICE, "device %d is %s; the kernels are built for gfx950 only", device,
+                    prop.gcnArchName);
+    mcamd_ctx *ctx = new (std::nothrow) mcamd_ctx;
+    if (!ctx) return fail(MCAMD_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+    if (hip_stream) {
+        ctx->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return fail(MCAMD_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        ctx->own_stream = true;
+    }
+    hipError_t e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_out, 2 * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_out, 2 * sizeof(double), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        mcamd_ctx_destroy(ctx);
+        return fail(MCAMD_ERR_HIP, "context setup: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return MCAMD_OK;
+}
+
+int mcamd_ctx_destroy(mcamd_ctx *ctx)
+{
+    if (!ctx) return MCAMD_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MCAMD_OK;
+}
+
+int mcamd_get_device_info(mcamd_ctx *ctx, mcamd_device_info *info)
+{
+    if (!ctx || !info) return fail(MCAMD_ERR_INVALID, "ctx and info must be non-NULL");
+    std::memset(info, 0, sizeof *info);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, ctx->device));
+    std::snprintf(info->name, sizeof info->name, "%s", p.name);
+    std::snprintf(info->arch, sizeof info->arch, "%s", p.gcnArchName);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    info->total_mem = total_b;
+    info->free_mem = free_b;
+    info->compute_units = p.multiProcessorCount;
+    info->wavefront_size = p.warpSize;
+    info->max_threads_per_block = p.maxThreadsPerBlock;
+    info->clock_khz = p.clockRate;
+    info->mem_clock_khz = p.memoryClockRate;
+    info->mem_bus_bits = p.memoryBusWidth;
+    info->lds_per_block = static_cast<int32_t>(p.sharedMemPerBlock);
+    info->regs_per_block = p.regsPerBlock;
+    info->l2_bytes = p.l2CacheSize;
+    info->device_index = ctx->device;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    info->device_count = count;
+    return MCAMD_OK;
+}
+
+int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, mcamd_result *res)
+{
+    if (int rc = check_common(ctx, opt, sim, res)) return rc;
+    zero_result(res);
+    if (sim->n_paths_local == 0) return MCAMD_OK;  // empty shard: all-zero statistics
+    HIP_TRY(hipSetDevice(ctx->device));
+    const mcamd::PathJob job = make_job(opt, sim);
+    const uint32_t grid = mcamd::price_grid(job.n_local);
+    if (int rc = ensure_partials(ctx, grid)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(mcamd::launch_price(job, ctx->d_partials, grid, ctx->stream));
+    if (int rc = finish(ctx, grid, res)) return rc;
+    const float kms = res->kernel_ms, tms = res->total_ms;
+    finalize_into(res->sum, res->sumsq, sim->n_paths_local, opt->r, opt->T, res);
+    res->kernel_ms = kms;
+    res->total_ms = tms;
+    res->grid = grid;
+    res->block = 256;
+    return MCAMD_OK;
+}
+
+int mcamd_simulate_trajectories(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout,
+                                void *d_traj, int32_t *d_counts, void *d_payoffs, mcamd_result *res)
+{
+    if (int rc = check_common(ctx, opt, sim, res)) return rc;
+    if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
+        return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
+    zero_result(res);
+    if (sim->n_paths_local == 0) return MCAMD_OK;
+    if (!d_traj) return fail(MCAMD_ERR_INVALID, "d_traj is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    mcamd::PathJob job = make_job(opt, sim);
+    if (d_counts && !job.window) {
+        // counts requested for a European payoff: count against B but let every count pay
+        job.window = true;
+        job.P1 = INT32_MIN;
+        job.P2 = INT32_MAX;
+    }
+    const uint32_t grid = mcamd::store_grid(job.n_local, job.precision);
+    if (int rc = ensure_partials(ctx, grid)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(mcamd::launch_store(job, layout, d_traj, d_counts, d_payoffs, ctx->d_partials, grid, ctx->stream));
+    if (int rc = finish(ctx, grid, res)) return rc;
+    const float kms = res->kernel_ms, tms = res->total_ms;
+    finalize_into(res->sum, res->sumsq, sim->n_paths_local, opt->r, opt->T, res);
+    res->kernel_ms = kms;
+    res->total_ms = tms;
+    res->grid = grid;
+    res->block = 256;
+    return MCAMD_OK;
+}
+
+int mcamd_price_from_normals(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, const void *d_normals,
+                             void *d_payoffs, mcamd_result *res)
+{
+    if (int rc = check_common(ctx, opt, sim, res)) return rc;
+    zero_result(res);
+    if (sim->n_paths_local == 0) return MCAMD_OK;
+    if (!d_normals) return fail(MCAMD_ERR_INVALID, "d_normals is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const mcamd::PathJob job = make_job(opt, sim);
+    const uint32_t grid = mcamd::array_grid(job.n_local);
+    if (int rc = ensure_partials(ctx, grid)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(mcamd::launch_from_normals(job, d_normals, d_payoffs, ctx->d_partials, grid, ctx->stream));
+    if (int rc = finish(ctx, grid, res)) return rc;
+    const float kms = res->kernel_ms, tms = res->total_ms;
+    finalize_into(res->sum, res->sumsq, sim->n_paths_local, opt->r, opt->T, res);
+    res->kernel_ms = kms;
+    res->total_ms = tms;
+    res->grid = grid;
+    res->block = 256;
+    return MCAMD_OK;
+}
+
+int mcamd_generate_normals(mcamd_ctx *ctx, uint64_t seed, uint64_t n, int precision, void *d_out, float *kernel_ms)
+{
+    if (!ctx) return fail(MCAMD_ERR_INVALID, "ctx is NULL");
+    if (precision != MCAMD_F32 && precision != MCAMD_F64) return fail(MCAMD_ERR_INVALID, "bad precision %d", precision);
+    if (kernel_ms) *kernel_ms = 0.0f;
+    if (n == 0) return MCAMD_OK;
+    if (!d_out) return fail(MCAMD_ERR_INVALID, "d_out is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(mcamd::launch_generate_normals(seed, n, precision, d_out, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    return MCAMD_OK;
+}
+
+int mcamd_reduce_sum(mcamd_ctx *ctx, const void *d_in, uint64_t n, int precision, int variant, double *sum,
+                     float *kernel_ms)
+{
+    if (!ctx || !sum) return fail(MCAMD_ERR_INVALID, "ctx and sum must be non-NULL");
+    if (precision != MCAMD_F32 && precision != MCAMD_F64) return fail(MCAMD_ERR_INVALID, "bad precision %d", precision);
+    if (variant < MCAMD_REDUCE_SEQUENTIAL || variant > MCAMD_REDUCE_GRID_STRIDE)
+        return fail(MCAMD_ERR_INVALID, "reduce variant must be 3..6 (ReductionType), got %d", variant);
+    *sum = 0.0;
+    if (kernel_ms) *kernel_ms = 0.0f;
+    if (n == 0) return MCAMD_OK;
+    if (!d_in) return fail(MCAMD_ERR_INVALID, "d_in is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t grid = mcamd::reduce_grid(n, variant);
+    if (int rc = ensure_partials(ctx, grid)) return rc;
+    mcamd_result tmp;
+    zero_result(&tmp);
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(mcamd::launch_reduce(d_in, n, precision, variant, ctx->d_partials, grid, ctx->stream));
+    if (int rc = finish(ctx, grid, &tmp)) return rc;
+    *sum = tmp.sum;
+    if (kernel_ms) *kernel_ms = tmp.kernel_ms;
+    return MCAMD_OK;
+}
+
+int mcamd_nmc_inner(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout, int variant,
+                    const void *d_prices, const int32_t *d_counts, void *d_point_prices, mcamd_result *res)
+{
+    if (int rc = check_common(ctx, opt, sim, res)) return rc;
+    if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
+        return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
+    if (variant != MCAMD_NMC_WAVE_PER_POINT && variant != MCAMD_NMC_BLOCK_PER_POINT)
+        return fail(MCAMD_ERR_INVALID, "unknown nested-MC variant %d", variant);
+    if (opt->Tk != 0) return fail(MCAMD_ERR_INVALID, "nested MC expects outer trajectories stored from step 0 (Tk = 0)");
+    if (sim->n_paths_inner == 0) return fail(MCAMD_ERR_INVALID, "n_paths_inner must be >= 1");
+    zero_result(res);
+    if (sim->n_paths_local == 0) return MCAMD_OK;
+    if (!d_prices || !d_point_prices) return fail(MCAMD_ERR_INVALID, "d_prices and d_point_prices must be non-NULL");
+    if (opt->use_window && !d_counts) return fail(MCAMD_ERR_INVALID, "bullet window needs d_counts");
+    const uint64_t n_points = sim->n_paths_local * static_cast<uint64_t>(sim->n_steps);
+    if (n_points / sim->n_steps != sim->n_paths_local) return fail(MCAMD_ERR_INVALID, "point count overflows");
+    HIP_TRY(hipSetDevice(ctx->device));
+    mcamd::NmcJob job;
+    job.path = make_job(opt, sim);
+    job.n_inner = sim->n_paths_inner;
+    job.discount = std::exp(-opt->r * opt->T);
+    job.n_points = n_points;
+    const uint32_t grid = mcamd::nmc_grid(job, variant);
+    if (int rc = ensure_partials(ctx, grid)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(mcamd::launch_nmc_inner(job, layout, variant, d_prices, d_counts, d_point_prices, ctx->d_partials, grid,
+                                    ctx->stream));
+    if (int rc = finish(ctx, grid, res)) return rc;
+    res->n = n_points;
+    res->price = n_points ? res->sum / static_cast<double>(n_points) : 0.0;  // mean point price (diagnostic)
+    res->grid = grid;
+    res->block = 256;
+    return MCAMD_OK;
+}
+
+int mcamd_finalize(double sum, double sumsq, uint64_t n, double r, double T, mcamd_result *res)
+{
+    if (!res) return fail(MCAMD_ERR_INVALID, "res is NULL");
+    zero_result(res);
+    finalize_into(sum, sumsq, n, r, T, res);
+    return MCAMD_OK;
+}
+
+// Closed form, host.  Same operation order and the same mixed precision as the reference:
+// `0.5 * v * v` and `exp(-r * T)` are evaluated in double and narrowed (inc/BlackandScholes.hpp:37,42).
+float mcamd_cnd_f32(float x)
+{
+    const float p = 0.2316419f;
+    const float b1 = 0.31938153f, b2 = -0.356563782f, b3 = 1.781477937f, b4 = -1.821255978f, b5 = 1.330274429f;
+    const float one_over_sqrt_twopi = 0.39894228f;
+    const float t = 1.0f / (1.0f + p * std::fabs(x));
+    const float tail = one_over_sqrt_twopi * expf(-x * x / 2.0f) * t * (t * (t * (t * (t * b5 + b4) + b3) + b2) + b1);
+    return x >= 0.0f ? 1.0f - tail : tail;
+}
+
+float mcamd_bs_call_f32(float x0, float strike, float T, float r, float sigma)
+{
+    const float sqrtT = sqrtf(T);
+    const float d1 = static_cast<float>(
+        (static_cast<double>(logf(x0 / strike)) + (static_cast<double>(r) + 0.5 * sigma * sigma) * T) /
+        static_cast<double>(sigma * sqrtT));
+    const float d2 = d1 - sigma * sqrtT;
+    const float n1 = mcamd_cnd_f32(d1), n2 = mcamd_cnd_f32(d2);
+    return static_cast<float>(static_cast<double>(x0 * n1) -
+                              static_cast<double>(strike) * std::exp(static_cast<double>(-r * T)) * n2);
+}
+
+double mcamd_bs_call_f64(double x0, double strike, double T, double r, double sigma)
+{
+    const double sqrtT = std::sqrt(T);
+    const double d1 = (std::log(x0 / strike) + (r + 0.5 * sigma * sigma) * T) / (sigma * sqrtT);
+    const double d2 = d1 - sigma * sqrtT;
+    return x0 * 0.5 * std::erfc(-d1 / std::sqrt(2.0)) - strike * std::exp(-r * T) * 0.5 * std::erfc(-d2 / std::sqrt(2.0));
+}
+
+}  // extern "C"

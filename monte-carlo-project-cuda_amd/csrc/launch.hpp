@@ -1,0 +1,57 @@
+// launch.hpp — host-side launcher interface between the C ABI (capi.cpp) and the kernel
+// translation units.  Launchers only enqueue work on `stream`; they never synchronise or allocate.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcamd {
+
+// Everything a path kernel needs, in double; launchers narrow to the path precision.
+struct PathJob {
+    double drift, vol;   // (r - v^2/2) dt, v sqrt(dt)
+    double K, B, S_start;
+    int32_t P1, P2, Ik;
+    uint32_t n_sim;      // steps to simulate
+    uint32_t n_steps;    // job's N_STEPS (indexing of points)
+    uint64_t seed;
+    uint64_t path_offset;
+    uint64_t n_local;
+    bool window;
+    int precision;       // 32 / 64
+};
+
+constexpr uint32_t kMaxGrid = 1u << 20;  // blocks; beyond this the kernels grid-stride
+
+// number of (sum, sumsq) partial pairs a launch with this many local paths writes
+uint32_t price_grid(uint64_t n_local);
+hipError_t launch_price(const PathJob &job, double *d_partials, uint32_t grid, hipStream_t stream);
+
+uint32_t store_grid(uint64_t n_local, int precision);
+hipError_t launch_store(const PathJob &job, int layout, void *d_traj, int32_t *d_counts, void *d_payoffs,
+                        double *d_partials, uint32_t grid, hipStream_t stream);
+
+uint32_t array_grid(uint64_t n_local);
+hipError_t launch_from_normals(const PathJob &job, const void *d_normals, void *d_payoffs, double *d_partials,
+                               uint32_t grid, hipStream_t stream);
+
+// sums n_pairs (a, b) pairs into d_out[0..1]
+hipError_t launch_final_reduce(const double *d_partials, uint32_t n_pairs, double *d_out, hipStream_t stream);
+
+hipError_t launch_generate_normals(uint64_t seed, uint64_t n, int precision, void *d_out, hipStream_t stream);
+
+uint32_t reduce_grid(uint64_t n, int variant);
+hipError_t launch_reduce(const void *d_in, uint64_t n, int precision, int variant, double *d_partials, uint32_t grid,
+                         hipStream_t stream);
+
+struct NmcJob {
+    PathJob path;            // inner-path constants (seed = inner seed)
+    uint32_t n_inner;
+    double discount;         // exp(-r T)
+    uint64_t n_points;       // n_local * n_steps
+};
+uint32_t nmc_grid(const NmcJob &job, int variant);
+hipError_t launch_nmc_inner(const NmcJob &job, int layout, int variant, const void *d_prices, const int32_t *d_counts,
+                            void *d_point_prices, double *d_partials, uint32_t grid, hipStream_t stream);
+
+}  // namespace mcamd

@@ -1,0 +1,219 @@
+// mc_device.hpp — device-side building blocks shared by the gfx950 kernels:
+// Philox4x32-10 in registers, rocRAND-convention Box-Muller, GBM step, wave64 reductions.
+// gfx950 only: wavefront = 64 lanes, hard-coded.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcamd {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011).  Counter layout is rocRAND's: (block_lo, block_hi,
+// subsequence_lo, subsequence_hi); key = (seed_lo, seed_hi).  Replaces the per-thread
+// curandState + setup_kernel of the reference (inc/tool.cuh:192-195): no state lives in HBM.
+// The round keys depend only on the seed (a kernel argument), so they stay in SGPRs.
+// ---------------------------------------------------------------------------------------------
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1)
+{
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = static_cast<uint64_t>(M0) * c0;
+        const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
+        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+        c1 = static_cast<uint32_t>(p1);
+        c3 = static_cast<uint32_t>(p0);
+        c0 = n0;
+        c2 = n2;
+        k0 += W0;
+        k1 += W1;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ U4 philox_block(uint64_t seed, uint64_t subsequence, uint64_t block)
+{
+    return philox4x32_10(static_cast<uint32_t>(block), static_cast<uint32_t>(block >> 32),
+                         static_cast<uint32_t>(subsequence), static_cast<uint32_t>(subsequence >> 32),
+                         static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Box-Muller, rocRAND convention (rocrand_normal.h box_muller / box_muller_double):
+//   fp32: u = 2^-32 + x 2^-32, angle = 2 pi (2^-32 + y 2^-32), (sin, cos) * sqrt(-2 ln u)
+//   fp64: u = 2^-53 + v1 2^-53 with v1 = x ^ (y << 21); angle = pi * (2^-52 + v2 2^-52)
+// fp32 uses the hardware transcendental unit directly: v_log_f32 (log2), v_sqrt_f32 and
+// v_sin_f32 / v_cos_f32, whose operand is in revolutions, so the angle needs no 2 pi multiply
+// and no range reduction.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void box_muller(uint32_t x, uint32_t y, float &a, float &b)
+{
+    constexpr float k2pow32inv = 2.3283064365386963e-10f;
+    const float u = __builtin_fmaf(static_cast<float>(x), k2pow32inv, k2pow32inv);
+    const float rev = __builtin_fmaf(static_cast<float>(y), k2pow32inv, k2pow32inv);
+    // -2 ln u = (-2 ln 2) log2 u
+    const float s = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));
+    a = __builtin_amdgcn_sinf(rev) * s;
+    b = __builtin_amdgcn_cosf(rev) * s;
+}
+
+__device__ __forceinline__ void box_muller(const U4 &w, double &a, double &b)
+{
+    constexpr double k2pow53inv = 1.1102230246251565e-16;
+    const uint64_t v1 = static_cast<uint64_t>(w.x) ^ (static_cast<uint64_t>(w.y) << 21);
+    const uint64_t v2 = static_cast<uint64_t>(w.z) ^ (static_cast<uint64_t>(w.w) << 21);
+    const double u = __builtin_fma(static_cast<double>(v1), k2pow53inv, k2pow53inv);
+    const double t = __builtin_fma(static_cast<double>(v2), 2.0 * k2pow53inv, 2.0 * k2pow53inv);
+    const double s = sqrt(-2.0 * log(u));
+    double sn, cs;
+    sincospi(t, &sn, &cs);
+    a = sn * s;
+    b = cs * s;
+}
+
+// Normals of one Philox block: 4 fp32 (steps 4k..4k+3) or 2 fp64 (steps 2k, 2k+1).
+template <typename T>
+struct Normals;
+
+template <>
+struct Normals<float> {
+    static constexpr int kPerBlock = 4;
+    float z[4];
+    __device__ __forceinline__ void fill(uint64_t seed, uint64_t subsequence, uint64_t block)
+    {
+        const U4 w = philox_block(seed, subsequence, block);
+        box_muller(w.x, w.y, z[0], z[1]);
+        box_muller(w.z, w.w, z[2], z[3]);
+    }
+};
+
+template <>
+struct Normals<double> {
+    static constexpr int kPerBlock = 2;
+    double z[2];
+    __device__ __forceinline__ void fill(uint64_t seed, uint64_t subsequence, uint64_t block)
+    {
+        const U4 w = philox_block(seed, subsequence, block);
+        box_muller(w, z[0], z[1]);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// GBM step constants and the step itself:  St *= exp(drift + vol * G)
+// (inc/trajectories.cuh:146, :224, :302; one-step form :75).  For fp32 the constants are
+// pre-multiplied by log2(e) on the host so the step is v_fma_f32 + v_exp_f32 + v_mul_f32.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct StepConsts {
+    T drift;    // (r - v^2/2) dt          [fp32: times log2 e]
+    T vol;      // v sqrt(dt)              [fp32: times log2 e]
+    T K;        // strike
+    T B;        // barrier
+    T S_start;  // S0, or Sk when restarting
+    int32_t P1, P2, Ik;
+    uint32_t n_sim;  // steps to simulate = n_steps - Tk
+};
+
+__device__ __forceinline__ float gbm_step(float St, float G, const StepConsts<float> &c)
+{
+    return St * __builtin_amdgcn_exp2f(__builtin_fmaf(G, c.vol, c.drift));
+}
+
+__device__ __forceinline__ double gbm_step(double St, double G, const StepConsts<double> &c)
+{
+    return St * exp(__builtin_fma(G, c.vol, c.drift));
+}
+
+template <typename T, bool WINDOW>
+__device__ __forceinline__ T payoff(T St, int32_t count, const StepConsts<T> &c)
+{
+    T pay = St - c.K;
+    pay = pay > T(0) ? pay : T(0);
+    if (WINDOW) pay = (count >= c.P1 && count <= c.P2) ? pay : T(0);
+    return pay;
+}
+
+// Simulates n_sim steps of one path in registers from (St, count) on the Philox stream
+// (seed, subsequence) and returns its undiscounted payoff.  Step loop of
+// inc/trajectories.cuh:144-148 (and the inner loops inc/nmc.cuh:55-59, :335-339).
+template <typename T, bool WINDOW>
+__device__ __forceinline__ T simulate_path(const StepConsts<T> &c, uint64_t seed, uint64_t subsequence, T St,
+                                           int32_t count, uint32_t n_sim)
+{
+    constexpr int NB = Normals<T>::kPerBlock;
+    const uint32_t n_full = n_sim / NB;
+    Normals<T> nrm;
+    for (uint32_t k = 0; k < n_full; ++k) {
+        nrm.fill(seed, subsequence, k);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            St = gbm_step(St, nrm.z[j], c);
+            if (WINDOW) count += (c.B > St) ? 1 : 0;
+        }
+    }
+    const uint32_t rem = n_sim - n_full * NB;
+    if (rem) {
+        nrm.fill(seed, subsequence, n_full);
+#pragma unroll
+        for (int j = 0; j < NB - 1; ++j) {
+            if (static_cast<uint32_t>(j) < rem) {
+                St = gbm_step(St, nrm.z[j], c);
+                if (WINDOW) count += (c.B > St) ? 1 : 0;
+            }
+        }
+    }
+    return payoff<T, WINDOW>(St, count, c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reductions.  Replaces the 1024-entry shared-memory tree + warp-32 shuffle inlined into every
+// reference kernel (inc/trajectories.cuh:77-111 etc., inc/reduce.cuh): a wave64 shuffle
+// reduction, one LDS slot per wave, finished by the first wave.  Inactive lanes contribute 0 —
+// the work is predicated, never the reduction (the reference puts barriers inside
+// `if (idx < N_PATHS)`).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// Sums (a, b) over the block; the result is valid in thread 0.  BLOCK must be a multiple of 64.
+template <int BLOCK>
+__device__ __forceinline__ void block_sum2(double &a, double &b)
+{
+    constexpr int kWaves = BLOCK / kWave;
+    __shared__ double lds[2 * kWaves];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (kWaves == 1) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    if (lane == 0) {
+        lds[2 * wave] = a;
+        lds[2 * wave + 1] = b;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        a = lane < kWaves ? lds[2 * lane] : 0.0;
+        b = lane < kWaves ? lds[2 * lane + 1] : 0.0;
+#pragma unroll
+        for (int off = kWaves / 2; off > 0; off >>= 1) {
+            a += __shfl_down(a, off, kWave);
+            b += __shfl_down(b, off, kWave);
+        }
+    }
+}
+
+}  // namespace mcamd

@@ -1,0 +1,32 @@
+// path_consts.hpp — narrows a host-side PathJob to the per-precision kernel constants.
+#pragma once
+
+#include "launch.hpp"
+#include "mc_device.hpp"
+
+namespace mcamd {
+
+template <typename T>
+inline StepConsts<T> make_consts(const PathJob &j)
+{
+    // fp32 path: fold log2(e) into the exponent constants (the step uses v_exp_f32 = 2^x)
+    const double scale = sizeof(T) == 4 ? 1.4426950408889634 : 1.0;
+    StepConsts<T> c;
+    c.drift = static_cast<T>(j.drift * scale);
+    c.vol = static_cast<T>(j.vol * scale);
+    c.K = static_cast<T>(j.K);
+    c.B = static_cast<T>(j.B);
+    c.S_start = static_cast<T>(j.S_start);
+    c.P1 = j.P1;
+    c.P2 = j.P2;
+    c.Ik = j.Ik;
+    c.n_sim = j.n_sim;
+    return c;
+}
+
+inline uint32_t clamp_grid(uint64_t blocks)
+{
+    return static_cast<uint32_t>(blocks < 1 ? 1 : (blocks > kMaxGrid ? kMaxGrid : blocks));
+}
+
+}  // namespace mcamd

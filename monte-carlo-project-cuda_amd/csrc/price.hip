@@ -1,0 +1,89 @@
+// price.hip — in-register Monte Carlo pricing kernel for gfx950.
+//
+// One kernel fuses RNG -> GBM stepping -> payoff -> block reduction, like the reference's
+// simulateOptionPriceMultipleBlockGPUwithReduce (inc/trajectories.cuh:54-113, one exact step)
+// and simulateBulletOptionPriceMultipleBlockGPU[atomic] (inc/trajectories.cuh:115-271, N_STEPS
+// steps + barrier window).  Differences by design:
+//   - Philox counters in registers instead of a curandState array in HBM (no setup kernel);
+//   - the path is the unit of work, indexed by its 64-bit GLOBAL id, so any shard of any job
+//     draws the same numbers;
+//   - per-thread fp64 (sum, sumsq) -> wave64 shuffle -> one LDS slot per wave -> one partial pair
+//     per block, finished by a second tiny kernel: deterministic, no float atomics, no reliance
+//     on pre-zeroed memory (SURVEY 2.4-2,7);
+//   - the tail is handled by predicating the work, not the reduction.
+// HBM traffic: 16 B per block written.  The kernel is VALU-bound (integer multiplies of Philox,
+// transcendental ops of Box-Muller and exp).
+#include "path_consts.hpp"
+
+namespace mcamd {
+
+template <typename T>
+struct PriceArgs {
+    StepConsts<T> c;
+    uint64_t seed;
+    uint64_t path_offset;
+    uint64_t n_local;
+};
+
+template <typename T, bool WINDOW>
+__global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *__restrict__ partials)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    double s = 0.0, s2 = 0.0;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_local; i += stride) {
+        const double pay = static_cast<double>(simulate_path<T, WINDOW>(a.c, a.seed, a.path_offset + i, a.c.S_start, a.c.Ik, a.c.n_sim));
+        s += pay;
+        s2 = __builtin_fma(pay, pay, s2);
+    }
+    block_sum2<kBlock>(s, s2);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = s;
+        partials[2 * blockIdx.x + 1] = s2;
+    }
+}
+
+// Final pass: sums n_pairs (a, b) pairs with one block, fixed order -> deterministic.
+__global__ __launch_bounds__(kBlock) void final_reduce_kernel(const double *__restrict__ partials, uint32_t n_pairs,
+                                                             double *__restrict__ out)
+{
+    double s = 0.0, s2 = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_pairs; i += kBlock) {
+        s += partials[2 * i];
+        s2 += partials[2 * i + 1];
+    }
+    block_sum2<kBlock>(s, s2);
+    if (threadIdx.x == 0) {
+        out[0] = s;
+        out[1] = s2;
+    }
+}
+
+uint32_t price_grid(uint64_t n_local)
+{
+    return clamp_grid((n_local + kBlock - 1) / kBlock);
+}
+
+template <typename T>
+static hipError_t launch_price_t(const PathJob &j, double *d_partials, uint32_t grid, hipStream_t stream)
+{
+    PriceArgs<T> a{make_consts<T>(j), j.seed, j.path_offset, j.n_local};
+    if (j.window)
+        hipLaunchKernelGGL((price_kernel<T, true>), dim3(grid), dim3(kBlock), 0, stream, a, d_partials);
+    else
+        hipLaunchKernelGGL((price_kernel<T, false>), dim3(grid), dim3(kBlock), 0, stream, a, d_partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_price(const PathJob &j, double *d_partials, uint32_t grid, hipStream_t stream)
+{
+    return j.precision == 32 ? launch_price_t<float>(j, d_partials, grid, stream)
+                             : launch_price_t<double>(j, d_partials, grid, stream);
+}
+
+hipError_t launch_final_reduce(const double *d_partials, uint32_t n_pairs, double *d_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(kBlock), 0, stream, d_partials, n_pairs, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace mcamd

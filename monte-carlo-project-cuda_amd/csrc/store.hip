@@ -1,0 +1,167 @@
+// store.hip — trajectory-store kernel for gfx950: every St (and optionally every running
+// barrier count) goes to HBM.
+//
+// Replaces simulateOptionPriceMultipleBlockGPU (trajectory overload, inc/testing.cuh:46-73:
+// prices only) and simulate_outer_trajectories (inc/trajectories.cuh:273-351: prices + counts,
+// the nested-MC outer stage).  The reference writes path-major, a[idx * N_STEPS + i]
+// (inc/trajectories.cuh:304-305): consecutive lanes are N_STEPS elements apart, so every lane
+// touches its own cache line.  Native layout here is step-major, a[step * n_local + path]:
+// a thread owns 16 bytes' worth of consecutive paths (4 fp32 / 2 fp64), so each step is one
+// 16 B-per-lane store and a wavefront writes 1 KiB contiguous — the widest coalesced store the
+// memory pipeline has.  The path-major layout stays available for callers that need the
+// reference's indexing (CSV dump, small tests); it is not the fast path.
+//
+// Same Philox counters as price.hip (subsequence = global path id), so a stored trajectory's
+// last row is bit-identical to the in-register path's terminal price.
+// Algorithmic HBM traffic: sizeof(T) bytes per path-step (+4 with counts) + sizeof(T) per path
+// payoff; no reads.  This is the bandwidth-bound configuration (BASELINE config 3).
+#include "path_consts.hpp"
+
+#include "mcamd.h"
+
+namespace mcamd {
+
+template <typename T>
+struct StoreArgs {
+    StepConsts<T> c;
+    uint64_t seed;
+    uint64_t path_offset;
+    uint64_t n_local;
+    T *traj;
+    int32_t *counts;
+    T *payoffs;
+    bool vec_ok;  // rows are 16-byte aligned: vector stores allowed
+};
+
+// One step row: the thread's V consecutive paths.  Streaming data: written once, never re-read
+// by this kernel, so the stores are non-temporal (keeps L2 for nothing, frees it from write-back
+// allocation churn).
+template <typename E, int V>
+__device__ __forceinline__ void store_row(E *row_base, uint64_t base, const E (&val)[V], bool vec_ok, int n_valid)
+{
+    if (vec_ok && n_valid == V) {
+        using VT = E __attribute__((ext_vector_type(V)));
+        VT pack;
+#pragma unroll
+        for (int p = 0; p < V; ++p) pack[p] = val[p];
+        __builtin_nontemporal_store(pack, reinterpret_cast<VT *>(row_base + base));
+    } else {
+#pragma unroll
+        for (int p = 0; p < V; ++p)
+            if (p < n_valid) __builtin_nontemporal_store(val[p], row_base + base + p);
+    }
+}
+
+template <typename T, bool WINDOW, int LAYOUT>
+__global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *__restrict__ partials)
+{
+    constexpr int V = 16 / sizeof(T);
+    constexpr int NB = Normals<T>::kPerBlock;
+    const StepConsts<T> &c = a.c;
+    const uint64_t n_groups = (a.n_local + V - 1) / V;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    const uint32_t n_blocks = (c.n_sim + NB - 1) / NB;
+    double s = 0.0, s2 = 0.0;
+
+    for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; g < n_groups; g += stride) {
+        const uint64_t base = g * V;
+        const int n_valid = (a.n_local - base >= static_cast<uint64_t>(V)) ? V : static_cast<int>(a.n_local - base);
+        T St[V];
+        int32_t cnt[V];
+#pragma unroll
+        for (int p = 0; p < V; ++p) {
+            St[p] = c.S_start;
+            cnt[p] = c.Ik;
+        }
+        for (uint32_t k = 0; k < n_blocks; ++k) {
+            Normals<T> nrm[V];
+#pragma unroll
+            for (int p = 0; p < V; ++p) nrm[p].fill(a.seed, a.path_offset + base + p, k);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const uint32_t step = k * NB + j;
+                if (step < c.n_sim) {
+#pragma unroll
+                    for (int p = 0; p < V; ++p) {
+                        St[p] = gbm_step(St[p], nrm[p].z[j], c);
+                        if (WINDOW) cnt[p] += (c.B > St[p]) ? 1 : 0;
+                    }
+                    if (LAYOUT == MCAMD_STEP_MAJOR) {
+                        store_row<T, V>(a.traj + static_cast<uint64_t>(step) * a.n_local, base, St, a.vec_ok, n_valid);
+                        if (WINDOW && a.counts)
+                            store_row<int32_t, V>(a.counts + static_cast<uint64_t>(step) * a.n_local, base, cnt,
+                                                  a.vec_ok, n_valid);
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < V; ++p)
+                            if (p < n_valid) {
+                                const uint64_t idx = (base + p) * c.n_sim + step;
+                                a.traj[idx] = St[p];
+                                if (WINDOW && a.counts) a.counts[idx] = cnt[p];
+                            }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < V; ++p)
+            if (p < n_valid) {
+                const T pay = payoff<T, WINDOW>(St[p], cnt[p], c);
+                if (a.payoffs) a.payoffs[base + p] = pay;
+                const double pd = static_cast<double>(pay);
+                s += pd;
+                s2 = __builtin_fma(pd, pd, s2);
+            }
+    }
+    block_sum2<kBlock>(s, s2);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = s;
+        partials[2 * blockIdx.x + 1] = s2;
+    }
+}
+
+uint32_t store_grid(uint64_t n_local, int precision)
+{
+    const uint64_t v = precision == 32 ? 4 : 2;
+    const uint64_t groups = (n_local + v - 1) / v;
+    return clamp_grid((groups + kBlock - 1) / kBlock);
+}
+
+template <typename T>
+static hipError_t launch_store_t(const PathJob &j, int layout, void *d_traj, int32_t *d_counts, void *d_payoffs,
+                                 double *d_partials, uint32_t grid, hipStream_t stream)
+{
+    constexpr uint64_t V = 16 / sizeof(T);
+    StoreArgs<T> a;
+    a.c = make_consts<T>(j);
+    a.seed = j.seed;
+    a.path_offset = j.path_offset;
+    a.n_local = j.n_local;
+    a.traj = static_cast<T *>(d_traj);
+    a.counts = d_counts;
+    a.payoffs = static_cast<T *>(d_payoffs);
+    a.vec_ok = (j.n_local % V == 0) && (reinterpret_cast<uintptr_t>(d_traj) % 16 == 0) &&
+               (d_counts == nullptr || reinterpret_cast<uintptr_t>(d_counts) % 16 == 0);
+    const dim3 g(grid), b(kBlock);
+    if (layout == MCAMD_STEP_MAJOR) {
+        if (j.window)
+            hipLaunchKernelGGL((store_kernel<T, true, MCAMD_STEP_MAJOR>), g, b, 0, stream, a, d_partials);
+        else
+            hipLaunchKernelGGL((store_kernel<T, false, MCAMD_STEP_MAJOR>), g, b, 0, stream, a, d_partials);
+    } else {
+        if (j.window)
+            hipLaunchKernelGGL((store_kernel<T, true, MCAMD_PATH_MAJOR>), g, b, 0, stream, a, d_partials);
+        else
+            hipLaunchKernelGGL((store_kernel<T, false, MCAMD_PATH_MAJOR>), g, b, 0, stream, a, d_partials);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_store(const PathJob &j, int layout, void *d_traj, int32_t *d_counts, void *d_payoffs,
+                        double *d_partials, uint32_t grid, hipStream_t stream)
+{
+    return j.precision == 32 ? launch_store_t<float>(j, layout, d_traj, d_counts, d_payoffs, d_partials, grid, stream)
+                             : launch_store_t<double>(j, layout, d_traj, d_counts, d_payoffs, d_partials, grid, stream);
+}
+
+}  // namespace mcamd

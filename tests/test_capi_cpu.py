@@ -1,0 +1,92 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/mcamd.h declares, keeps its struct layout, and its host-only entry points (closed form,
+finalize, argument errors) behave.  No kernels are launched here."""
+import ctypes as C
+import importlib
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pkg = importlib.import_module("monte-carlo-project-cuda_amd")
+capi = pkg.capi
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(capi.LIB_PATH):
+        pkg.build()
+    return capi.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "mcamd.h")).read()
+    declared = set(re.findall(r"\b(mcamd_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mcamd_abi_version() == 1
+
+
+def test_struct_layout_is_the_documented_abi():
+    assert C.sizeof(capi.Option) == 80 and C.sizeof(capi.Sim) == 48
+    assert C.sizeof(capi.Result) == 72 and C.sizeof(capi.DeviceInfo) == 384
+
+
+def test_closed_form_matches_reference_golden_bitwise(lib, golden):
+    g = golden("bs_closed_form.json")
+    for c in g["call"]:
+        assert np.float32(capi.bs_call_f32(c["S0"], c["K"], c["T"], c["r"], c["sigma"])) == np.float32(c["ref_call_f32"])
+    for c in g["cnd"]:
+        assert np.float32(capi.cnd_f32(c["x"])) == np.float32(c["ref_cnd_f32"])
+    assert abs(capi.bs_call_f64(100, 100, 1, 0.1, 0.2) - 13.269676584660893) < 1e-11
+
+
+def test_closed_form_matches_oracle(lib, oracle):
+    rng = np.random.default_rng(11)
+    for _ in range(500):
+        a = [float(np.float32(x)) for x in (rng.uniform(10, 300), rng.uniform(10, 300), rng.uniform(0.05, 4),
+                                            rng.uniform(0, 0.15), rng.uniform(0.05, 0.9))]
+        assert np.float32(capi.bs_call_f32(*a)) == np.float32(oracle.bs_call_f32(*a))
+        assert math.isclose(capi.bs_call_f64(*a), oracle.bs_call_f64(*a), rel_tol=1e-14, abs_tol=1e-300)
+
+
+def test_finalize_matches_oracle(lib, oracle):
+    x = np.random.default_rng(3).gamma(2.0, 8.0, size=1000)
+    res = capi.finalize(float(x.sum()), float((x * x).sum()), x.size, 0.1, 1.0)
+    want = oracle.finalize(float(x.sum()), float((x * x).sum()), x.size, 0.1, 1.0)
+    for k in ("price", "std_err", "ci_lo", "ci_hi"):
+        assert math.isclose(getattr(res, k), want[k], rel_tol=1e-15)
+    assert math.isclose(res.std_err, math.exp(-0.1) * x.std(ddof=1) / math.sqrt(x.size), rel_tol=1e-10)
+    empty = capi.finalize(0.0, 0.0, 0, 0.1, 1.0)
+    assert empty.price == 0.0 and empty.std_err == 0.0 and empty.n == 0
+
+
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(capi.McamdError) as e:
+        capi.Context(0)
+    assert e.value.code == capi.ERR_NODEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_null_arguments_are_errors_not_crashes(lib):
+    assert lib.mcamd_price_paths(None, None, None, None) == capi.ERR_INVALID
+    assert b"NULL" in lib.mcamd_last_error()
+    assert lib.mcamd_finalize(0.0, 0.0, 0, 0.0, 1.0, None) == capi.ERR_INVALID
+    assert lib.mcamd_reduce_sum(None, None, 0, 32, 6, None, None) == capi.ERR_INVALID
+    assert lib.mcamd_ctx_destroy(None) == capi.OK
+
+
+def test_product_does_not_reach_into_the_oracle():
+    # the shipped package and headers must not import, link or call anything under oracle/
+    for base in ("monte-carlo-project-cuda_amd", "include"):
+        for d, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                    text = open(os.path.join(d, f)).read()
+                    assert "pyoracle" not in text and "liboracle" not in text and "oracle/" not in text, (d, f)

@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Benchmark driver.  `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
+
+A "step" is one pass of the hot path over one batch: every rank prices its shard of a European
+call (S0=K=100, T=1, r=0.1, sigma=0.2 — hello.cu:6-10) through the C ABI (mcamd_price_paths):
+Philox RNG -> 252 GBM steps -> payoff -> fp64 (sum, sumsq), nothing stored — BASELINE.json
+configs[1] (10M paths, 252 steps, fp64, in-register) per GPU.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) the global job is N x 10M paths sharded by contiguous
+global path id, and each step ends with ONE all-reduce of (sum, sumsq, n) over RCCL; weak scaling.
+Inputs are a handful of scalars, so nothing crosses PCIe in the timed region except the 16-byte
+result of each call.
+
+Extra objects on the line:
+  roofline      the dominant kernel (price_kernel<double,false>) against the VALU issue roofline
+                (this path has ~zero HBM traffic and no matrix work), from HIP events recorded
+                inside the library on the launch stream;
+  roofline_store  one untimed pass of BASELINE configs[2] (100M paths x 252 steps fp32 stored
+                step-major, 101.2 GB) against the HBM roofline — the bandwidth-bound path;
+  cpu_baseline  the reference's own CPU Monte Carlo (oracle/_ref, kind "reference") or the oracle
+                port, timed on this host on a bounded sample of the same workload, rank 0, N=1 only.
+Other workloads: --workload store | nmc | vanilla1 (see --help).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BS_EXACT = 13.269676584660893  # closed form, fp64, benchmark option
+OPTION = dict(S0=100.0, T=1.0, K=100.0, r=0.1, v=0.2)
+
+# VALU issue roofline (MI355X_MICROARCH.md): 256 CUs x 4 SIMD-32 x 2.4 GHz; a wave64 VALU
+# instruction issues in 2 cycles at full rate -> 32 lane-ops / cycle / SIMD.
+PEAK_VALU_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 78.6 Tlane-op/s (= 157.3 TFLOP/s fp32 FMA / 2)
+PEAK_HBM_GBS = 8000.0
+
+# Full-rate-equivalent VALU issue slots per path-step of the shipped kernels, counted from the
+# gfx950 ISA of the inner loop (profiles/isa_r01.md explains the count and the rate weights).
+W_SLOTS = {"price_f64": None, "price_f32": None}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="european252",
+                    choices=["european252", "european252_f32", "vanilla1", "store", "nmc"])
+    ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-store-roofline", action="store_true")
+    ap.add_argument("--cpu-sample-paths", type=int, default=0)
+    return ap.parse_args()
+
+
+def load_w_slots():
+    path = os.path.join(ROOT, "profiles", "valu_slots.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            W_SLOTS.update(json.load(f))
+
+
+def cpu_baseline(n_steps: int, sample_paths: int):
+    """Times the CPU path on this host: reference build if present, else the oracle port."""
+    from oracle import pyoracle as o
+    out = {}
+    ref = o.ref_cpumc()
+    cores_avail = os.cpu_count() or 1
+    if ref is not None:
+        n = sample_paths or (2_000_000 if n_steps > 1 else 50_000_000)
+        t0 = time.perf_counter()
+        if n_steps > 1:
+            # reference CPU multi-step pricer with the barrier window wide open = European call
+            price = ref.ref_simulateBulletOptionPriceCPU(100.0, 1.0, 100.0, 0.1, 0.2, 0.0, 0, n_steps, n, n_steps)
+        else:
+            price = ref.ref_simulateOptionPriceCPU(100.0, 1.0, 100.0, 0.1, 0.2, n)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": n / dt, "unit": "paths/s", "cores": 1, "kind": "reference",
+            "sample": f"{n} paths x {n_steps} steps, fp32, mt19937, reference inc/tool.cuh:"
+                      f"{'133-173' if n_steps > 1 else '104-130'} compiled as oracle/_ref, {dt:.1f} s",
+            "price": float(price), "host_cores_available": cores_avail}
+    threads = o.max_threads()
+    n = sample_paths or (threads * 150_000 if n_steps > 1 else 20_000_000)
+    p = o.make_params(n_paths=n, n_steps=n_steps, seed=1234)
+    t0 = time.perf_counter()
+    res = o.mc_paths(p, 64, 0, n, threads=threads)
+    dt = time.perf_counter() - t0
+    fin = o.finalize(res["sum"], res["sumsq"], n, 0.1, 1.0)
+    port = {"value": n / dt, "unit": "paths/s", "cores": threads, "kind": "port",
+            "sample": f"{n} paths x {n_steps} steps, fp64, Philox (same stream as the GPU), OpenMP, {dt:.1f} s",
+            "price": fin["price"], "host_cores_available": cores_avail}
+    if "cpu_baseline" in out:
+        out["cpu_baseline_port"] = port
+    else:
+        out["cpu_baseline"] = port
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    pkg = importlib.import_module("monte-carlo-project-cuda_amd")
+    capi = pkg.capi
+    load_w_slots()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = args.workload
+    prec = capi.F32 if wl in ("european252_f32", "store") else capi.F64
+    n_steps = 1 if wl == "vanilla1" else 252
+    default_paths = {"european252": 10_000_000, "european252_f32": 10_000_000, "vanilla1": 100_000_000,
+                     "store": 100_000_000, "nmc": 2048}
+    per_gpu = args.paths or default_paths[wl]
+    n_total = per_gpu * world
+    lo = rank * per_gpu
+    opt = capi.make_option(**OPTION)
+    stream = torch.cuda.current_stream()
+    ctx = capi.Context(local_rank, stream.cuda_stream)
+    stats = torch.zeros(3, dtype=torch.float64, device="cuda")
+
+    traj = None
+    nmc_bufs = None
+    if wl == "store":
+        traj = torch.empty(per_gpu * n_steps, dtype=torch.float32, device="cuda")
+    if wl == "nmc":
+        n_steps, n_inner = 252, 1000
+        wopt = capi.make_option(**OPTION, B=0.0, P1=0, P2=n_steps, use_window=1)  # European-window variant
+        tr = torch.empty(per_gpu * n_steps, dtype=torch.float64, device="cuda")
+        cn = torch.empty(per_gpu * n_steps, dtype=torch.int32, device="cuda")
+        pp = torch.empty(per_gpu * n_steps, dtype=torch.float64, device="cuda")
+        nmc_bufs = (wopt, tr, cn, pp, n_inner)
+
+    def one_step(i: int):
+        seed = 1234 + i
+        if wl == "store":
+            sim = capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu)
+            res = ctx.simulate_trajectories(opt, sim, traj)
+        elif wl == "nmc":
+            wopt, tr, cn, pp, n_inner = nmc_bufs
+            ctx.simulate_trajectories(wopt, capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu), tr, cn)
+            res = ctx.nmc_inner(wopt, capi.make_sim(n_total, n_steps, prec, seed + 1, lo, per_gpu, n_inner), tr, cn, pp)
+        else:
+            sim = capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu)
+            res = ctx.price_paths(opt, sim)
+        if world > 1:
+            stats[0], stats[1], stats[2] = res.sum, res.sumsq, float(res.n)
+            dist.all_reduce(stats)  # the one collective of the path: (sum, sumsq, n) over RCCL/xGMI
+            s, s2, n = (float(x) for x in stats.tolist())
+            fin = capi.finalize(s, s2, int(n), opt.r, opt.T)
+        else:
+            fin = res
+        return res, fin
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(-1 - i)
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    fin = None
+    for i in range(args.steps):
+        res, fin = one_step(i)
+        kernel_ms.append(res.kernel_ms)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    line = None
+    if rank == 0:
+        units = per_gpu * world * args.steps
+        avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+        line = {
+            "metric": "MC paths/sec, European call (price error vs closed-form BS reported)",
+            "value": units / elapsed, "unit": "paths/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if prec == capi.F32 else "f64", "data": "synthetic",
+            "config": {"workload": {"european252": "European call, 10M paths/GPU x 252 steps, fp64, in-register (BASELINE configs[1])",
+                                    "european252_f32": "European call, 252 steps, fp32, in-register",
+                                    "vanilla1": "European call, 1 exact step, fp64, in-register",
+                                    "store": "European call, 100M paths x 252 steps, fp32, trajectories stored step-major (BASELINE configs[2])",
+                                    "nmc": "nested MC, outer paths x 252 steps x 1000 inner, fp64 (BASELINE configs[3] shape)"}[wl],
+                       "paths_per_gpu": per_gpu, "n_steps": n_steps, "global_paths": n_total,
+                       "sharding": f"path-id ranges over {world} rank(s), one RCCL all-reduce of (sum,sumsq,n) per step"
+                       if world > 1 else "single GPU", "seed": "1234+step", "rng": "Philox4x32-10, subsequence = global path id"},
+            "path_steps_per_s": units * n_steps / elapsed,
+            "kernel_ms_avg": avg_kernel_s * 1e3,
+        }
+        if wl != "nmc":
+            line.update({"price": fin.price, "std_err": fin.std_err, "ci95": [fin.ci_lo, fin.ci_hi],
+                         "bs_closed_form": BS_EXACT, "abs_err_vs_bs": abs(fin.price - BS_EXACT),
+                         "within_3se": abs(fin.price - BS_EXACT) <= 3 * fin.std_err,
+                         "within_1e-4": abs(fin.price - BS_EXACT) <= 1e-4})
+        # roofline of the dominant kernel, from the library's HIP events on the launch stream
+        if wl == "store":
+            bytes_per_launch = per_gpu * n_steps * 4 + 16 * res.grid
+            ach = bytes_per_launch / avg_kernel_s / 1e9
+            line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                                "kernel": "store_kernel<float,false,STEP_MAJOR>",
+                                "algorithmic_bytes_per_launch": bytes_per_launch}
+        elif wl in ("european252", "european252_f32"):
+            key = "price_f64" if prec == capi.F64 else "price_f32"
+            w = W_SLOTS.get(key)
+            steps_per_s = per_gpu * n_steps / avg_kernel_s
+            rl = {"bound": "valu", "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s", "traffic": None,
+                  "kernel": f"price_kernel<{'double' if prec == capi.F64 else 'float'},false>",
+                  "path_steps_per_s_kernel": steps_per_s, "valu_slots_per_path_step": w}
+            if w:
+                rl["achieved"] = steps_per_s * w / 1e12
+                rl["frac"] = rl["achieved"] / PEAK_VALU_TLANEOPS
+            else:
+                rl["achieved"] = None
+                rl["frac"] = None
+            line["roofline"] = rl
+
+    # bandwidth-bound path, one untimed pass of configs[2] beside the headline (N=1 only)
+    if world == 1 and wl == "european252" and not args.no_store_roofline:
+        try:
+            n3, s3 = 100_000_000, 252
+            free, _ = torch.cuda.mem_get_info()
+            if free > n3 * s3 * 4 + (4 << 30):
+                buf = torch.empty(n3 * s3, dtype=torch.float32, device="cuda")
+                sim3 = capi.make_sim(n3, s3, capi.F32, 1234)
+                ctx.simulate_trajectories(opt, sim3, buf)
+                ks = []
+                for _ in range(3):
+                    r3 = ctx.simulate_trajectories(opt, sim3, buf)
+                    ks.append(r3.kernel_ms)
+                kms = sum(ks) / len(ks)
+                nbytes = n3 * s3 * 4 + 16 * r3.grid
+                ach = nbytes / (kms / 1e3) / 1e9
+                line["roofline_store"] = {
+                    "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                    "traffic": None, "kernel": "store_kernel<float,false,STEP_MAJOR>", "kernel_ms": kms,
+                    "workload": "BASELINE configs[2]: 100M paths x 252 steps fp32 stored step-major",
+                    "algorithmic_bytes_per_launch": nbytes, "paths_per_s": n3 / (kms / 1e3),
+                    "price": r3.price, "std_err": r3.std_err, "abs_err_vs_bs": abs(r3.price - BS_EXACT)}
+                del buf
+        except Exception as e:  # the headline must survive a failure of the side measurement
+            line["roofline_store"] = {"error": str(e)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line.update(cpu_baseline(n_steps, args.cpu_sample_paths))
+
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,14 @@ int mcamd_ctx_create(int device, void *hip_stream, mcamd_ctx **ctx);
 int mcamd_ctx_destroy(mcamd_ctx *ctx);
 int mcamd_get_device_info(mcamd_ctx *ctx, mcamd_device_info *info);
 
+/* Device memory helpers so that a host program needs nothing but this library (the reference's
+ * wrappers call cudaMalloc / cudaMemcpy / cudaFree directly: inc/wrappers.cuh:39,49,55).
+ * Copies are synchronous with respect to the context's stream. */
+int mcamd_device_malloc(mcamd_ctx *ctx, uint64_t bytes, void **d_ptr);
+int mcamd_device_free(mcamd_ctx *ctx, void *d_ptr);
+int mcamd_memcpy_to_host(mcamd_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+int mcamd_memcpy_to_device(mcamd_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+
 /* In-register Monte Carlo: RNG -> GBM steps -> payoff -> fp64 (sum, sumsq); nothing is stored.
  * Replaces the kernel + host tail of
  *   wrapper_gpu_option_vanilla          inc/wrappers.cuh:33-57   (n_steps = 1)

@@ -1,0 +1,162 @@
+// tool.hpp — host-side mirror of the reference's inc/tool.cuh on top of the mcamd C ABI.
+// Same names and argument meaning; the GPU work behind them runs in libmcamd.so (gfx950).
+//   OptionData                     inc/tool.cuh:13-26   (same fields, same order, 48 bytes)
+//   printOptionData                inc/tool.cuh:29-44
+//   getDeviceProperty              inc/tool.cuh:56-88   (hipDeviceProp via mcamd_get_device_info)
+//   simulateOptionPriceCPU         inc/tool.cuh:104-130 (serial CPU MC, one exact step)
+//   simulateBulletOptionPriceCPU   inc/tool.cuh:133-173 (serial CPU MC, N_STEPS steps + window)
+//   get_max_blocks                 inc/tool.cuh:176-188
+//   isPow2 / nextPow2              inc/tool.cuh:200-210
+// setup_kernel (inc/tool.cuh:192-195) has no counterpart: the engine's Philox counters live in
+// registers, there is no RNG state to initialise.  Errors never exit() the process: a failed
+// engine call makes the wrapper return -1.0f (the reference's launch-error value,
+// inc/wrappers.cuh:77) and leaves the message in mcamd_last_error().
+#pragma once
+
+#include "mcamd.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <iostream>
+#include <random>
+
+struct OptionData {
+    float S0;
+    float T;
+    float K;
+    float r;
+    float v;
+    float B;
+    int P1;
+    int P2;
+    int N_PATHS;
+    int N_PATHS_INNER;
+    int N_STEPS;
+    float step;
+};
+static_assert(sizeof(OptionData) == 48, "OptionData must keep the reference's 48-byte layout");
+
+namespace mcamd_shim {
+
+// Print switch: the reference's wrappers always print their result (inc/wrappers.cuh:16,28,52,...);
+// the shim does too unless this is cleared.
+inline bool &verbose()
+{
+    static bool v = true;
+    return v;
+}
+
+// One lazily created context on device 0, shared by every shim call of the process.
+inline mcamd_ctx *context()
+{
+    static mcamd_ctx *ctx = nullptr;
+    if (!ctx && mcamd_ctx_create(0, nullptr, &ctx) != MCAMD_OK) {
+        std::fprintf(stderr, "mcamd: %s\n", mcamd_last_error());
+        ctx = nullptr;
+    }
+    return ctx;
+}
+
+inline mcamd_option to_option(const OptionData &od, bool window)
+{
+    mcamd_option o{};
+    o.S0 = od.S0; o.T = od.T; o.K = od.K; o.r = od.r; o.v = od.v; o.B = od.B;
+    o.P1 = od.P1; o.P2 = od.P2;
+    o.use_window = window ? 1 : 0;
+    return o;
+}
+
+inline mcamd_sim to_sim(uint64_t n_paths, uint32_t n_steps, uint64_t seed, int precision, uint32_t n_inner = 0)
+{
+    mcamd_sim s{};
+    s.n_paths = n_paths; s.path_offset = 0; s.n_paths_local = n_paths;
+    s.n_steps = n_steps; s.n_paths_inner = n_inner; s.seed = seed; s.precision = precision;
+    return s;
+}
+
+// Serial CPU Monte Carlo in fp32 with std::mt19937 + std::normal_distribution<float>, seeded from
+// std::random_device like the reference (so it is not reproducible run to run).  n_steps == 1 with
+// window == false is the one-step vanilla pricer.
+inline float cpu_monte_carlo(const OptionData &od, int n_steps, float dt, bool window)
+{
+    std::mt19937 gen(std::random_device{}());
+    std::normal_distribution<float> gauss(0.0f, 1.0f);
+    const float drift = (od.r - (od.v * od.v) / 2) * dt;
+    const float vol = od.v * std::sqrt(dt);
+    float acc = 0.0f;
+    for (int p = 0; p < od.N_PATHS; ++p) {
+        float s = od.S0;
+        int below = 0;
+        for (int k = 0; k < n_steps; ++k) {
+            s *= std::exp(drift + vol * gauss(gen));
+            below += (window && s < od.B) ? 1 : 0;
+        }
+        const bool pays = !window || (below >= od.P1 && below <= od.P2);
+        if (pays && s > od.K) acc += s - od.K;
+    }
+    return std::exp(-od.r * od.T) * acc / static_cast<float>(od.N_PATHS);
+}
+
+}  // namespace mcamd_shim
+
+inline void printOptionData(OptionData od)
+{
+    std::cout << "\nS0 : " << od.S0 << "\nT : " << od.T << "\nK : " << od.K << "\nr : " << od.r << "\nv : " << od.v
+              << "\nB : " << od.B << "\nP1 : " << od.P1 << "\nP2 : " << od.P2 << "\nN_PATHS : " << od.N_PATHS
+              << "\nN_PATHS_INNER : " << od.N_PATHS_INNER << "\nN_STEPS : " << od.N_STEPS << "\nstep : " << od.step
+              << "\n\n";
+}
+
+inline void getDeviceProperty()
+{
+    mcamd_ctx *ctx = mcamd_shim::context();
+    mcamd_device_info di;
+    if (!ctx || mcamd_get_device_info(ctx, &di) != MCAMD_OK) {
+        std::fprintf(stderr, "mcamd: %s\n", mcamd_last_error());
+        return;
+    }
+    const double GIGA = 1024.0 * 1024.0 * 1024.0;
+    std::printf("The number of devices available is %d GPUs \n", di.device_count);
+    std::printf("Name: %s (%s)\n", di.name, di.arch);
+    std::printf("Global memory size in bytes: %fGB (free %fGB)\n", di.total_mem / GIGA, di.free_mem / GIGA);
+    std::printf("LDS size per block: %d\n", di.lds_per_block);
+    std::printf("Number of registers per block: %d\n", di.regs_per_block);
+    std::printf("Number of threads in a wavefront: %d\n", di.wavefront_size);
+    std::printf("Maximum number of threads that can be launched per block: %d\n", di.max_threads_per_block);
+    std::printf("Clock rate: %d kHz, memory clock %d kHz, memory bus %d bits\n", di.clock_khz, di.mem_clock_khz,
+                di.mem_bus_bits);
+    std::printf("L2 size: %d\n", di.l2_bytes);
+    std::printf("Number of compute units: %d\n", di.compute_units);
+}
+
+inline void simulateOptionPriceCPU(float *optionPriceCPU, OptionData option_data)
+{
+    *optionPriceCPU = mcamd_shim::cpu_monte_carlo(option_data, 1, option_data.T, false);
+}
+
+inline void simulateBulletOptionPriceCPU(float *optionPriceCPU, OptionData option_data)
+{
+    *optionPriceCPU = mcamd_shim::cpu_monte_carlo(option_data, option_data.N_STEPS, option_data.step, true);
+}
+
+// The reference sizes its grid by how many curandState fit in 90% of free memory.  There is no
+// state array here; the free/total print is kept and the return value is what the same formula
+// gives for a 64-byte state, so callers that only print or cap with it keep working.
+inline size_t get_max_blocks(int threads_per_block)
+{
+    mcamd_ctx *ctx = mcamd_shim::context();
+    mcamd_device_info di;
+    if (!ctx || mcamd_get_device_info(ctx, &di) != MCAMD_OK) return 0;
+    const double GIGA = 1024.0 * 1024.0 * 1024.0;
+    std::printf("free_mem: %7.3fGB, total_mem: %7.3fGB\n", di.free_mem / GIGA, di.total_mem / GIGA);
+    return static_cast<size_t>(di.free_mem * 0.90) / (64u * static_cast<size_t>(threads_per_block));
+}
+
+inline bool isPow2(unsigned int x) { return (x & (x - 1)) == 0; }
+
+inline unsigned int nextPow2(unsigned int x)
+{
+    if (x <= 1) return 1;
+    return 1u << (32 - __builtin_clz(x - 1));
+}

@@ -21,7 +21,8 @@ REDUCE_SEQUENTIAL, REDUCE_FIRST_ADD, REDUCE_UNROLL_LAST, REDUCE_GRID_STRIDE = 3,
 # every symbol include/mcamd.h declares
 EXPORTS = [
     "mcamd_abi_version", "mcamd_last_error", "mcamd_device_count", "mcamd_ctx_create", "mcamd_ctx_destroy",
-    "mcamd_get_device_info", "mcamd_price_paths", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
+    "mcamd_get_device_info", "mcamd_device_malloc", "mcamd_device_free", "mcamd_memcpy_to_host",
+    "mcamd_memcpy_to_device", "mcamd_price_paths", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
     "mcamd_generate_normals", "mcamd_reduce_sum", "mcamd_nmc_inner", "mcamd_finalize", "mcamd_cnd_f32",
     "mcamd_bs_call_f32", "mcamd_bs_call_f64",
 ]
@@ -82,6 +83,10 @@ def load() -> C.CDLL:
     L.mcamd_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
     L.mcamd_ctx_destroy.argtypes = [vp]
     L.mcamd_get_device_info.argtypes = [vp, C.POINTER(DeviceInfo)]
+    L.mcamd_device_malloc.argtypes = [vp, u64, C.POINTER(vp)]
+    L.mcamd_device_free.argtypes = [vp, vp]
+    L.mcamd_memcpy_to_host.argtypes = [vp, vp, vp, u64]
+    L.mcamd_memcpy_to_device.argtypes = [vp, vp, vp, u64]
     L.mcamd_price_paths.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), C.POINTER(Result)]
     L.mcamd_simulate_trajectories.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, vp, vp, vp,
                                               C.POINTER(Result)]

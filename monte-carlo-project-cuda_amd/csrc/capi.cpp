@@ -12,6 +12,10 @@
 #include <cstring>
 #include <string>
 
+static_assert(sizeof(mcamd_option) == 80 && sizeof(mcamd_sim) == 48 && sizeof(mcamd_result) == 72 &&
+                  sizeof(mcamd_device_info) == 384,
+              "C ABI struct layout changed: bump MCAMD_ABI_VERSION");
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -250,6 +254,48 @@ int mcamd_get_device_info(mcamd_ctx *ctx, mcamd_device_info *info)
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     info->device_count = count;
+    return MCAMD_OK;
+}
+
+int mcamd_device_malloc(mcamd_ctx *ctx, uint64_t bytes, void **d_ptr)
+{
+    if (!ctx || !d_ptr) return fail(MCAMD_ERR_INVALID, "ctx and d_ptr must be non-NULL");
+    *d_ptr = nullptr;
+    if (bytes == 0) return MCAMD_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(d_ptr, bytes));
+    return MCAMD_OK;
+}
+
+int mcamd_device_free(mcamd_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return fail(MCAMD_ERR_INVALID, "ctx is NULL");
+    if (!d_ptr) return MCAMD_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_ptr));
+    return MCAMD_OK;
+}
+
+int mcamd_memcpy_to_host(mcamd_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes)
+{
+    if (!ctx) return fail(MCAMD_ERR_INVALID, "ctx is NULL");
+    if (bytes == 0) return MCAMD_OK;
+    if (!h_dst || !d_src) return fail(MCAMD_ERR_INVALID, "copy pointers must be non-NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MCAMD_OK;
+}
+
+int mcamd_memcpy_to_device(mcamd_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes)
+{
+    if (!ctx) return fail(MCAMD_ERR_INVALID, "ctx is NULL");
+    if (bytes == 0) return MCAMD_OK;
+    if (!d_dst || !h_src) return fail(MCAMD_ERR_INVALID, "copy pointers must be non-NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MCAMD_OK;
 }
 

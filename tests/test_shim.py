@@ -1,0 +1,69 @@
+"""The C++ shim (include/*.hpp) re-exposes the reference's call surface over the C ABI.
+CPU: the two re-created drivers compile with plain g++ against libmcamd.so.
+GPU: they run; hello prints every label hello.cu prints with sane values, testing exits 0
+(its own GPU-vs-CPU checks) and writes the reference's CSV format."""
+import importlib
+import math
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+EX = os.path.join(ROOT, "examples")
+pkg = importlib.import_module("monte-carlo-project-cuda_amd")
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(pkg.capi.LIB_PATH):
+        pkg.build()
+    subprocess.check_call(["make", "-C", EX, "-s", "all"])
+    return EX
+
+
+def test_shim_drivers_compile_with_gxx(built):
+    assert os.path.exists(os.path.join(built, "hello")) and os.path.exists(os.path.join(built, "testing"))
+
+
+def test_shim_headers_cite_reference_lines():
+    for h in ("tool.hpp", "wrappers.hpp", "testing.hpp", "BlackandScholes.hpp", "monte_carlo.hpp", "option_price.hpp"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        assert re.search(r"inc/\w+\.(cuh|hpp)", text) and re.search(r":\d+-\d+", text), h
+
+
+@pytest.mark.gpu
+def test_hello_runs_and_prices_are_sane(built):
+    out = subprocess.run([os.path.join(built, "hello")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    vals = {}
+    for label in ("Average CPU Vanilla Option", "Monte Carlo CPU Bullet Option Price", "Average GPU",
+                  "Average GPU bullet option", "Average GPU bullet option atomic",
+                  "Average GPU bullet option nmc one point per block", "Average GPU bullet option nmc one kernel",
+                  "Average GPU bullet option nmc optimal", "call Black Scholes"):
+        m = re.search(re.escape(label) + r"\s*:\s*([-0-9.e+]+)", out.stdout)
+        assert m, (label, out.stdout)
+        vals[label] = float(m.group(1))
+    se = 16.109 / math.sqrt(100000)
+    assert abs(vals["call Black Scholes"] - 13.2697) < 1e-3
+    assert abs(vals["Average GPU"] - 13.2697) < 4 * se
+    assert abs(vals["Average CPU Vanilla Option"] - 13.2697) < 5 * se
+    assert abs(vals["Average GPU bullet option"] - vals["Monte Carlo CPU Bullet Option Price"]) < 0.25
+    assert vals["Average GPU bullet option"] == vals["Average GPU bullet option atomic"]
+    a, b, c = (vals[k] for k in ("Average GPU bullet option nmc one point per block",
+                                 "Average GPU bullet option nmc one kernel", "Average GPU bullet option nmc optimal"))
+    assert a == b and abs(a - c) < 1e-3 * max(1.0, abs(a)) and a > 0
+    assert "fp64 vanilla" in out.stdout
+
+
+@pytest.mark.gpu
+def test_testing_driver_passes_and_writes_csv(built, tmp_path):
+    out = subprocess.run([os.path.join(built, "testing")], capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "FAIL" not in out.stdout
+    rows = open(tmp_path / "testing.csv").read().strip().split("\n")
+    assert rows[0] == "time,trajectory,value"
+    assert len(rows) == 1 + 20 * 151            # t=0 row + 150 steps for each of 20 trajectories
+    assert rows[1].split(",")[0] == "0" and float(rows[1].split(",")[2]) == 100.0

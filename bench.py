@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--workload", default="european252",
                     choices=["european252", "european252_f32", "vanilla1", "store", "nmc"])
     ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the config's)")
+    ap.add_argument("--global-paths", type=int, default=0,
+                    help="strong scaling: total paths per step, split over the ranks by contiguous path id "
+                         "(e.g. 1000000000 for BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-store-roofline", action="store_true")
     ap.add_argument("--cpu-sample-paths", type=int, default=0)
@@ -132,13 +135,17 @@ def main():
     n_steps = 1 if wl == "vanilla1" else 252
     default_paths = {"european252": 10_000_000, "european252_f32": 10_000_000, "vanilla1": 100_000_000,
                      "store": 100_000_000, "nmc": 2048}
-    per_gpu = args.paths or default_paths[wl]
-    n_total = per_gpu * world
-    lo = rank * per_gpu
+    sharding = pkg.sharding
+    if args.global_paths:
+        n_total = args.global_paths
+        lo, per_gpu = sharding.shard_range(n_total, world, rank)   # strong scaling
+    else:
+        per_gpu = args.paths or default_paths[wl]                  # weak scaling: fixed work per GPU
+        n_total = per_gpu * world
+        lo = rank * per_gpu
     opt = capi.make_option(**OPTION)
     stream = torch.cuda.current_stream()
     ctx = capi.Context(local_rank, stream.cuda_stream)
-    stats = torch.zeros(3, dtype=torch.float64, device="cuda")
 
     traj = None
     nmc_bufs = None
@@ -165,10 +172,9 @@ def main():
             sim = capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu)
             res = ctx.price_paths(opt, sim)
         if world > 1:
-            stats[0], stats[1], stats[2] = res.sum, res.sumsq, float(res.n)
-            dist.all_reduce(stats)  # the one collective of the path: (sum, sumsq, n) over RCCL/xGMI
-            s, s2, n = (float(x) for x in stats.tolist())
-            fin = capi.finalize(s, s2, int(n), opt.r, opt.T)
+            # the one collective of the path: (sum, sumsq, n), three doubles, over RCCL/xGMI
+            s, s2, n = sharding.allreduce_stats(res.sum, res.sumsq, res.n, device="cuda")
+            fin = capi.finalize(s, s2, n, opt.r, opt.T)
         else:
             fin = res
         return res, fin
@@ -196,13 +202,13 @@ def main():
 
     line = None
     if rank == 0:
-        units = per_gpu * world * args.steps
+        units = n_total * args.steps
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
         line = {
             "metric": "MC paths/sec, European call (price error vs closed-form BS reported)",
             "value": units / elapsed, "unit": "paths/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": "strong" if args.global_paths else "weak", "vs_baseline": None,
             "dtype": "f32" if prec == capi.F32 else "f64", "data": "synthetic",
             "config": {"workload": {"european252": "European call, 10M paths/GPU x 252 steps, fp64, in-register (BASELINE configs[1])",
                                     "european252_f32": "European call, 252 steps, fp32, in-register",

@@ -7,5 +7,6 @@ The directory name carries a hyphen, so import it with
 """
 from . import build as _build  # noqa: F401
 from . import capi  # noqa: F401
+from . import sharding  # noqa: F401
 
 build = _build.build

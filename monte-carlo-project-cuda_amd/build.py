@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libmcamd.so")
 SOURCES = ["price.hip", "store.hip", "aux.hip", "nmc.hip", "capi.cpp"]
-HEADERS = ["launch.hpp", "mc_device.hpp", "path_consts.hpp"]
+HEADERS = ["launch.hpp", "mc_device.hpp", "path_consts.hpp", "fast64.hpp", "tables64.inc", "tables64_consts.inc"]
 ARCH = "gfx950"
 
 

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
     constexpr int kRowsPerLoad = kWave / TS;   // path rows one wave-wide load covers
     __shared__ T tile[kWaves][kWave][TS + 1];
     const StepConsts<T> &c = a.c;
+    const MathCtx<T> m = MathCtx<T>::init();
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const int lcol = lane % TS, lrow = lane / TS;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (my_path < a.n_local) {
                 for (uint32_t j = 0; j < n_cols; ++j) {
-                    St = gbm_step(St, tile[wave][lane][j], c);
+                    St = gbm_step(St, tile[wave][lane][j], c, m);
                     if (WINDOW) count += (c.B > St) ? 1 : 0;
                 }
             }
@@ -111,11 +112,12 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void normals_kernel(uint64_t seed, uint64_t n, T *__restrict__ out, bool vec_ok)
 {
     constexpr int NB = Normals<T>::kPerBlock;
+    const MathCtx<T> m = MathCtx<T>::init();
     const uint64_t n_blocks = (n + NB - 1) / NB;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; k < n_blocks; k += stride) {
         Normals<T> nrm;
-        nrm.fill(seed, 0, k);
+        nrm.fill(m, seed, 0, k);
         const uint64_t base = k * NB;
         if (vec_ok && base + NB <= n) {
             using VT = T __attribute__((ext_vector_type(NB)));

@@ -1,0 +1,164 @@
+// fast64.hpp — hand-written fp64 elementary functions for the pricing kernels' inner loop.
+//
+// Why: on gfx950 the in-register fp64 path is bound by VALU issue (every fp64 op costs 4 cycles per
+// wave64, profiles/r01_valu_issue_costs.json), and the device libm's log / sincospi / exp spend a
+// large share of their instructions on cases this loop cannot produce (denormals, NaN/Inf, huge
+// arguments) and on table-free polynomials.  These versions use the argument ranges the
+// Box-Muller / GBM step actually has, and move part of the work off the VALU onto the LDS pipe:
+// three 128-entry tables (5 KB per workgroup) give short polynomials.
+//
+//   neg2log(u)        -2 ln u          u in [2^-53, 1]                 11 fp64 ops
+//   sqrt_pos(a)       sqrt(a)          a >= 0 (clamped to >= 1e-300)   v_rsq_f64 + 8 fp64 ops
+//   sincos_q(q)       sin, cos(pi q/64)  q = 64 t, t in (0, 2]         16 fp64 ops
+//   mul_exp(S, x)     S * e^x          |x| < 700                       13 fp64 ops
+// Accuracy (tests/test_fast64.py, against long-double libm on 4M random arguments each):
+// <= 2 ulp for neg2log / mul_exp, <= 1 ulp sqrt_pos, <= 2e-16 absolute for sin / cos.
+//
+// The header compiles for the host too (plain g++), with the tables as ordinary arrays and the
+// hardware reciprocal square root emulated at reduced precision, so the numerics are unit-tested
+// on the CPU without a GPU.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MC_HD __host__ __device__ __forceinline__
+#else
+#include <cmath>
+#define MC_HD inline
+#endif
+
+namespace mcamd {
+namespace f64 {
+
+struct alignas(16) D2 {
+    double a, b;
+};
+
+// Pointers to the three tables: LDS copies inside a kernel, the static arrays on the host.
+struct Tables {
+    const D2 *log_tab;     // {-2/c_i, -2 ln c_i}
+    const D2 *sincos_tab;  // {sin, cos}(2 pi j / 128)
+    const double *exp_tab; // 2^(j/128)
+};
+
+MC_HD uint32_t hi32(double x)
+{
+    uint64_t b;
+    __builtin_memcpy(&b, &x, 8);
+    return static_cast<uint32_t>(b >> 32);
+}
+
+MC_HD uint32_t lo32(double x)
+{
+    uint64_t b;
+    __builtin_memcpy(&b, &x, 8);
+    return static_cast<uint32_t>(b);
+}
+
+MC_HD double make_double(uint32_t lo, uint32_t hi)
+{
+    const uint64_t b = (static_cast<uint64_t>(hi) << 32) | lo;
+    double x;
+    __builtin_memcpy(&x, &b, 8);
+    return x;
+}
+
+MC_HD double rsq_seed(double a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsq(a);  // v_rsq_f64
+#else
+    return static_cast<double>(static_cast<float>(1.0 / __builtin_sqrt(a)));  // ~24-bit seed, like the hardware op
+#endif
+}
+
+// (v + 1) * c_lo with v = x ^ (y << 21) the 53-bit integer rocRAND builds from two Philox words
+// (rocrand_normal.h box_muller_double); c_hi = 2^32 c_lo.  Exact: v + 1 <= 2^53.
+//   u = (v+1) 2^-53  -> c_lo = 2^-53      (Box-Muller radius uniform, in (0, 1])
+//   q = (v+1) 2^-46  -> c_lo = 2^-46      (64 x the angle uniform t = (v+1) 2^-52 in (0, 2])
+MC_HD double u53(uint32_t x, uint32_t y, double c_hi, double c_lo)
+{
+    const uint32_t lo = x ^ (y << 21);
+    const uint32_t hi = y >> 11;
+    return __builtin_fma(static_cast<double>(hi), c_hi, __builtin_fma(static_cast<double>(lo), c_lo, c_lo));
+}
+
+#include "tables64_consts.inc"
+
+// -2 ln(u) for u in [2^-53, 1].  u = 2^k z, z in [0.6875, 1.375); chunk i of z's bit pattern selects
+// c_i; t = -2 (z / c_i - 1) is tiny (|t| < 2^-7), and -2 ln(1 - t/2) = t + t^2/4 + t^3/12 + ...
+MC_HD double neg2log(double u, const D2 *tab)
+{
+    const uint32_t hx = hi32(u);
+    const uint32_t tmp = hx - 0x3fe60000u;
+    const uint32_t i = (tmp >> 13) & 127u;
+    const int32_t k = static_cast<int32_t>(tmp) >> 20;
+    const double z = make_double(lo32(u), hx - (tmp & 0xfff00000u));
+    const D2 e = tab[i];
+    const double t = __builtin_fma(z, e.a, 2.0);
+    const double w = __builtin_fma(static_cast<double>(k), kM2Ln2, e.b);
+    double q = __builtin_fma(t, 1.0 / 448.0, 1.0 / 192.0);
+    q = __builtin_fma(t, q, 1.0 / 80.0);
+    q = __builtin_fma(t, q, 1.0 / 32.0);
+    q = __builtin_fma(t, q, 1.0 / 12.0);
+    q = __builtin_fma(t, q, 0.25);
+    return w + __builtin_fma(t * t, q, t);
+}
+
+// sqrt(a), a >= 0: hardware reciprocal-sqrt seed, one coupled Newton step, one correction.
+MC_HD double sqrt_pos(double a)
+{
+    a = __builtin_fmax(a, 1e-300);  // a == 0 (u == 1, probability 2^-53) must not reach rsq
+    const double y = rsq_seed(a);
+    double g = a * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, a);
+    return __builtin_fma(d, h, g);
+}
+
+// sin and cos of pi * t given q = 64 t (exact), t in (0, 2]: angle = (2 pi / 128)(j + f),
+// j = rint(q), f = q - j in [-1/2, 1/2]; table gives sin/cos of the node, short Taylor sums the rest.
+MC_HD void sincos_q(double q, const D2 *tab, double &s, double &c)
+{
+    const double j = __builtin_rint(q);
+    const double f = q - j;
+    const int32_t ji = static_cast<int32_t>(j);
+    const D2 e = tab[ji & 127];
+    const double d = f * kPiOver64;
+    const double z = d * d;
+    double sp = __builtin_fma(z, -1.0 / 5040.0, 1.0 / 120.0);
+    sp = __builtin_fma(z, sp, -1.0 / 6.0);
+    const double sd = __builtin_fma(d * z, sp, d);
+    double cp = __builtin_fma(z, -1.0 / 720.0, 1.0 / 24.0);
+    cp = __builtin_fma(z, cp, -0.5);
+    const double cd = __builtin_fma(z, cp, 1.0);
+    s = __builtin_fma(e.a, cd, e.b * sd);
+    c = __builtin_fma(e.b, cd, -(e.a * sd));
+}
+
+// S * exp(x): x = (k / 128) ln 2 + r, |r| <= ln2 / 256; 2^(k/128) = 2^(k >> 7) * table[k & 127].
+MC_HD double mul_exp(double S, double x, const double *tab)
+{
+    const double kd = __builtin_rint(x * kNOverLn2);
+    const int32_t ki = static_cast<int32_t>(kd);
+    double r = __builtin_fma(kd, -kLn2OverN_hi, x);
+    r = __builtin_fma(kd, -kLn2OverN_lo, r);
+    const double tv = tab[ki & 127];
+    const uint32_t bump = (static_cast<uint32_t>(ki) & 0xffffff80u) << 13;  // (k >> 7) << 20
+    const double sc = make_double(lo32(tv), hi32(tv) + bump);
+    const double r2 = r * r;
+    const double p = __builtin_fma(r, 1.0 / 6.0, 0.5);
+    const double pq = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    double tmp = __builtin_fma(r2, p, r);
+    tmp = __builtin_fma(r2 * r2, pq, tmp);
+    const double Ss = S * sc;
+    return __builtin_fma(Ss, tmp, Ss);
+}
+
+}  // namespace f64
+}  // namespace mcamd

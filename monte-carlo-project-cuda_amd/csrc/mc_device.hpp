@@ -6,7 +6,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fast64.hpp"
+
 namespace mcamd {
+
+#define MCAMD_TAB_DECL static __device__ const
+#include "tables64.inc"
+#undef MCAMD_TAB_DECL
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
@@ -29,8 +35,9 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     for (int i = 0; i < 10; ++i) {
         const uint64_t p0 = static_cast<uint64_t>(M0) * c0;
         const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
-        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+        // three-input xor in one full-rate instruction (v_bitop3_b32, truth table 0x96)
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p0 >> 32), c3, k1, 0x96);
         c1 = static_cast<uint32_t>(p1);
         c3 = static_cast<uint32_t>(p0);
         c0 = n0;
@@ -49,10 +56,40 @@ __device__ __forceinline__ U4 philox_block(uint64_t seed, uint64_t subsequence, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Per-workgroup math context.  The fp64 path uses the table-driven functions of fast64.hpp; their
+// three 128-entry tables (5 KB) are copied into LDS once per workgroup, so the per-lane lookups
+// run on the LDS pipe beside the VALU.  The fp32 path needs nothing (hardware transcendentals).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct MathCtx {
+    __device__ __forceinline__ static MathCtx init() { return MathCtx{}; }
+};
+
+template <>
+struct MathCtx<double> {
+    f64::Tables t;
+    // Must be called by every thread of the workgroup (contains a barrier).
+    __device__ __forceinline__ static MathCtx init()
+    {
+        __shared__ f64::D2 s_log[MCAMD_TAB_N];
+        __shared__ f64::D2 s_sincos[MCAMD_TAB_N];
+        __shared__ double s_exp[MCAMD_TAB_N];
+        for (int i = threadIdx.x; i < MCAMD_TAB_N; i += blockDim.x) {
+            s_log[i] = f64::D2{kLogTab[i][0], kLogTab[i][1]};
+            s_sincos[i] = f64::D2{kSinCosTab[i][0], kSinCosTab[i][1]};
+            s_exp[i] = kExp2Tab[i];
+        }
+        __syncthreads();
+        return MathCtx{f64::Tables{s_log, s_sincos, s_exp}};
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Box-Muller, rocRAND convention (rocrand_normal.h box_muller / box_muller_double):
 //   fp32: u = 2^-32 + x 2^-32, angle = 2 pi (2^-32 + y 2^-32), (sin, cos) * sqrt(-2 ln u)
 //   fp64: u = 2^-53 + v1 2^-53 with v1 = x ^ (y << 21); angle = pi * (2^-52 + v2 2^-52)
-// fp32 uses the hardware transcendental unit directly: v_log_f32 (log2), v_sqrt_f32 and
+// fp64 uses the table-driven functions of fast64.hpp (u and the angle are exact, the elementary
+// functions are within 2 ulp of libm).  fp32 uses the hardware transcendental unit directly: v_log_f32 (log2), v_sqrt_f32 and
 // v_sin_f32 / v_cos_f32, whose operand is in revolutions, so the angle needs no 2 pi multiply
 // and no range reduction.
 // ---------------------------------------------------------------------------------------------
@@ -67,16 +104,13 @@ __device__ __forceinline__ void box_muller(uint32_t x, uint32_t y, float &a, flo
     b = __builtin_amdgcn_cosf(rev) * s;
 }
 
-__device__ __forceinline__ void box_muller(const U4 &w, double &a, double &b)
+__device__ __forceinline__ void box_muller(const U4 &w, const MathCtx<double> &m, double &a, double &b)
 {
-    constexpr double k2pow53inv = 1.1102230246251565e-16;
-    const uint64_t v1 = static_cast<uint64_t>(w.x) ^ (static_cast<uint64_t>(w.y) << 21);
-    const uint64_t v2 = static_cast<uint64_t>(w.z) ^ (static_cast<uint64_t>(w.w) << 21);
-    const double u = __builtin_fma(static_cast<double>(v1), k2pow53inv, k2pow53inv);
-    const double t = __builtin_fma(static_cast<double>(v2), 2.0 * k2pow53inv, 2.0 * k2pow53inv);
-    const double s = sqrt(-2.0 * log(u));
+    const double u = f64::u53(w.x, w.y, 0x1p-21, 0x1p-53);   // (v1 + 1) 2^-53, exact
+    const double q = f64::u53(w.z, w.w, 0x1p-14, 0x1p-46);   // 64 (v2 + 1) 2^-52, exact
+    const double s = f64::sqrt_pos(f64::neg2log(u, m.t.log_tab));
     double sn, cs;
-    sincospi(t, &sn, &cs);
+    f64::sincos_q(q, m.t.sincos_tab, sn, cs);
     a = sn * s;
     b = cs * s;
 }
@@ -89,7 +123,7 @@ template <>
 struct Normals<float> {
     static constexpr int kPerBlock = 4;
     float z[4];
-    __device__ __forceinline__ void fill(uint64_t seed, uint64_t subsequence, uint64_t block)
+    __device__ __forceinline__ void fill(const MathCtx<float> &, uint64_t seed, uint64_t subsequence, uint64_t block)
     {
         const U4 w = philox_block(seed, subsequence, block);
         box_muller(w.x, w.y, z[0], z[1]);
@@ -101,10 +135,11 @@ template <>
 struct Normals<double> {
     static constexpr int kPerBlock = 2;
     double z[2];
-    __device__ __forceinline__ void fill(uint64_t seed, uint64_t subsequence, uint64_t block)
+    __device__ __forceinline__ void fill(const MathCtx<double> &m, uint64_t seed, uint64_t subsequence,
+                                         uint64_t block)
     {
         const U4 w = philox_block(seed, subsequence, block);
-        box_muller(w, z[0], z[1]);
+        box_muller(w, m, z[0], z[1]);
     }
 };
 
@@ -124,14 +159,14 @@ struct StepConsts {
     uint32_t n_sim;  // steps to simulate = n_steps - Tk
 };
 
-__device__ __forceinline__ float gbm_step(float St, float G, const StepConsts<float> &c)
+__device__ __forceinline__ float gbm_step(float St, float G, const StepConsts<float> &c, const MathCtx<float> &)
 {
     return St * __builtin_amdgcn_exp2f(__builtin_fmaf(G, c.vol, c.drift));
 }
 
-__device__ __forceinline__ double gbm_step(double St, double G, const StepConsts<double> &c)
+__device__ __forceinline__ double gbm_step(double St, double G, const StepConsts<double> &c, const MathCtx<double> &m)
 {
-    return St * exp(__builtin_fma(G, c.vol, c.drift));
+    return f64::mul_exp(St, __builtin_fma(G, c.vol, c.drift), m.t.exp_tab);
 }
 
 template <typename T, bool WINDOW>
@@ -147,27 +182,27 @@ __device__ __forceinline__ T payoff(T St, int32_t count, const StepConsts<T> &c)
 // (seed, subsequence) and returns its undiscounted payoff.  Step loop of
 // inc/trajectories.cuh:144-148 (and the inner loops inc/nmc.cuh:55-59, :335-339).
 template <typename T, bool WINDOW>
-__device__ __forceinline__ T simulate_path(const StepConsts<T> &c, uint64_t seed, uint64_t subsequence, T St,
-                                           int32_t count, uint32_t n_sim)
+__device__ __forceinline__ T simulate_path(const StepConsts<T> &c, const MathCtx<T> &m, uint64_t seed,
+                                           uint64_t subsequence, T St, int32_t count, uint32_t n_sim)
 {
     constexpr int NB = Normals<T>::kPerBlock;
     const uint32_t n_full = n_sim / NB;
     Normals<T> nrm;
     for (uint32_t k = 0; k < n_full; ++k) {
-        nrm.fill(seed, subsequence, k);
+        nrm.fill(m, seed, subsequence, k);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            St = gbm_step(St, nrm.z[j], c);
+            St = gbm_step(St, nrm.z[j], c, m);
             if (WINDOW) count += (c.B > St) ? 1 : 0;
         }
     }
     const uint32_t rem = n_sim - n_full * NB;
     if (rem) {
-        nrm.fill(seed, subsequence, n_full);
+        nrm.fill(m, seed, subsequence, n_full);
 #pragma unroll
         for (int j = 0; j < NB - 1; ++j) {
             if (static_cast<uint32_t>(j) < rem) {
-                St = gbm_step(St, nrm.z[j], c);
+                St = gbm_step(St, nrm.z[j], c, m);
                 if (WINDOW) count += (c.B > St) ? 1 : 0;
             }
         }

@@ -52,6 +52,7 @@ template <typename T, bool WINDOW, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *__restrict__ partials)
 {
     constexpr int kWaves = kBlock / kWave;
+    const MathCtx<T> m = MathCtx<T>::init();
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const uint64_t wave_stride = static_cast<uint64_t>(gridDim.x) * kWaves;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
         if (!WINDOW || cnt0 <= a.c.P2) {
             for (uint32_t j = lane; j < a.n_inner; j += kWave)
                 acc += static_cast<double>(
-                    simulate_path<T, WINDOW>(a.c, a.seed, point_id * a.n_inner + j, St0, cnt0, remaining));
+                    simulate_path<T, WINDOW>(a.c, m, a.seed, point_id * a.n_inner + j, St0, cnt0, remaining));
         }
         acc = wave_sum(acc);
         if (lane == 0) {
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
 template <typename T, bool WINDOW, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double *__restrict__ partials)
 {
+    const MathCtx<T> m = MathCtx<T>::init();
     double psum = 0.0, psumsq = 0.0;
     for (uint64_t task = blockIdx.x; task < a.n_points; task += gridDim.x) {
         uint32_t step;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
         if (!WINDOW || cnt0 <= a.c.P2) {
             for (uint32_t j = threadIdx.x; j < a.n_inner; j += kBlock)
                 acc += static_cast<double>(
-                    simulate_path<T, WINDOW>(a.c, a.seed, point_id * a.n_inner + j, St0, cnt0, remaining));
+                    simulate_path<T, WINDOW>(a.c, m, a.seed, point_id * a.n_inner + j, St0, cnt0, remaining));
         }
         block_sum2<kBlock>(acc, zero);
         if (threadIdx.x == 0) {

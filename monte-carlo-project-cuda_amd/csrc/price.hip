@@ -28,10 +28,12 @@ struct PriceArgs {
 template <typename T, bool WINDOW>
 __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *__restrict__ partials)
 {
+    const MathCtx<T> m = MathCtx<T>::init();
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     double s = 0.0, s2 = 0.0;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_local; i += stride) {
-        const double pay = static_cast<double>(simulate_path<T, WINDOW>(a.c, a.seed, a.path_offset + i, a.c.S_start, a.c.Ik, a.c.n_sim));
+        const double pay = static_cast<double>(
+            simulate_path<T, WINDOW>(a.c, m, a.seed, a.path_offset + i, a.c.S_start, a.c.Ik, a.c.n_sim));
         s += pay;
         s2 = __builtin_fma(pay, pay, s2);
     }

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *_
     constexpr int V = 16 / sizeof(T);
     constexpr int NB = Normals<T>::kPerBlock;
     const StepConsts<T> &c = a.c;
+    const MathCtx<T> m = MathCtx<T>::init();
     const uint64_t n_groups = (a.n_local + V - 1) / V;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     const uint32_t n_blocks = (c.n_sim + NB - 1) / NB;
@@ -76,14 +77,14 @@ __global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *_
         for (uint32_t k = 0; k < n_blocks; ++k) {
             Normals<T> nrm[V];
 #pragma unroll
-            for (int p = 0; p < V; ++p) nrm[p].fill(a.seed, a.path_offset + base + p, k);
+            for (int p = 0; p < V; ++p) nrm[p].fill(m, a.seed, a.path_offset + base + p, k);
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const uint32_t step = k * NB + j;
                 if (step < c.n_sim) {
 #pragma unroll
                     for (int p = 0; p < V; ++p) {
-                        St[p] = gbm_step(St[p], nrm[p].z[j], c);
+                        St[p] = gbm_step(St[p], nrm[p].z[j], c, m);
                         if (WINDOW) cnt[p] += (c.B > St[p]) ? 1 : 0;
                     }
                     if (LAYOUT == MCAMD_STEP_MAJOR) {

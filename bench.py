@@ -221,6 +221,11 @@ def main():
             "path_steps_per_s": units * n_steps / elapsed,
             "kernel_ms_avg": avg_kernel_s * 1e3,
         }
+        if wl == "nmc":
+            inner_steps = per_gpu * world * nmc_bufs[4] * (n_steps * (n_steps - 1) // 2)   # sum of remaining steps
+            line["inner_paths_per_s"] = per_gpu * world * n_steps * nmc_bufs[4] * args.steps / elapsed
+            line["inner_path_steps_per_s"] = inner_steps * args.steps / elapsed
+            line["mean_point_price"] = fin.price
         if wl != "nmc":
             line.update({"price": fin.price, "std_err": fin.std_err, "ci95": [fin.ci_lo, fin.ci_hi],
                          "bs_closed_form": BS_EXACT, "abs_err_vs_bs": abs(fin.price - BS_EXACT),
@@ -232,7 +237,7 @@ def main():
             ach = bytes_per_launch / avg_kernel_s / 1e9
             line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": ach / PEAK_HBM_GBS, "traffic": None,
-                                "kernel": "store_kernel<float,false,STEP_MAJOR>",
+                                "kernel": "store_kernel<float,false,STEP_MAJOR,vec>",
                                 "algorithmic_bytes_per_launch": bytes_per_launch}
         elif wl in ("european252", "european252_f32"):
             key = "price_f64" if prec == capi.F64 else "price_f32"
@@ -267,7 +272,7 @@ def main():
                 ach = nbytes / (kms / 1e3) / 1e9
                 line["roofline_store"] = {
                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                    "traffic": None, "kernel": "store_kernel<float,false,STEP_MAJOR>", "kernel_ms": kms,
+                    "traffic": None, "kernel": "store_kernel<float,false,STEP_MAJOR,vec>", "kernel_ms": kms,
                     "workload": "BASELINE configs[2]: 100M paths x 252 steps fp32 stored step-major",
                     "algorithmic_bytes_per_launch": nbytes, "paths_per_s": n3 / (kms / 1e3),
                     "price": r3.price, "std_err": r3.std_err, "abs_err_vs_bs": abs(r3.price - BS_EXACT)}

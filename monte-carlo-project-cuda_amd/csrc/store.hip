@@ -34,12 +34,11 @@ struct StoreArgs {
 };
 
 // One step row: the thread's V consecutive paths.  Streaming data: written once, never re-read
-// by this kernel, so the stores are non-temporal (keeps L2 for nothing, frees it from write-back
-// allocation churn).
-template <typename E, int V>
-__device__ __forceinline__ void store_row(E *row_base, uint64_t base, const E (&val)[V], bool vec_ok, int n_valid)
+// by this kernel, so the stores are non-temporal.
+template <typename E, int V, bool VEC>
+__device__ __forceinline__ void store_row(E *row_base, uint64_t base, const E (&val)[V], int n_valid)
 {
-    if (vec_ok && n_valid == V) {
+    if (VEC) {
         using VT = E __attribute__((ext_vector_type(V)));
         VT pack;
 #pragma unroll
@@ -52,7 +51,10 @@ __device__ __forceinline__ void store_row(E *row_base, uint64_t base, const E (&
     }
 }
 
-template <typename T, bool WINDOW, int LAYOUT>
+// VEC: every row is 16-byte aligned and n_local is a multiple of V, so each thread's group is full
+// and each step is exactly one 16 B store per lane with no per-lane predicate at all.  Otherwise
+// (ragged n_local or unaligned buffers) the same loop runs with guarded scalar stores.
+template <typename T, bool WINDOW, int LAYOUT, bool VEC>
 __global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *__restrict__ partials)
 {
     constexpr int V = 16 / sizeof(T);
@@ -61,12 +63,14 @@ __global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *_
     const MathCtx<T> m = MathCtx<T>::init();
     const uint64_t n_groups = (a.n_local + V - 1) / V;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    const uint32_t n_blocks = (c.n_sim + NB - 1) / NB;
+    const uint32_t n_full = c.n_sim / NB;         // Philox blocks whose NB steps are all simulated
+    const uint32_t rem = c.n_sim - n_full * NB;   // steps of the last, partial block
     double s = 0.0, s2 = 0.0;
 
     for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; g < n_groups; g += stride) {
         const uint64_t base = g * V;
-        const int n_valid = (a.n_local - base >= static_cast<uint64_t>(V)) ? V : static_cast<int>(a.n_local - base);
+        const int n_valid =
+            VEC ? V : ((a.n_local - base >= static_cast<uint64_t>(V)) ? V : static_cast<int>(a.n_local - base));
         T St[V];
         int32_t cnt[V];
 #pragma unroll
@@ -74,35 +78,40 @@ __global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *_
             St[p] = c.S_start;
             cnt[p] = c.Ik;
         }
-        for (uint32_t k = 0; k < n_blocks; ++k) {
+        auto advance = [&](const Normals<T>(&nrm)[V], int j, uint32_t step) {
+#pragma unroll
+            for (int p = 0; p < V; ++p) {
+                St[p] = gbm_step(St[p], nrm[p].z[j], c, m);
+                if (WINDOW) cnt[p] += (c.B > St[p]) ? 1 : 0;
+            }
+            if (LAYOUT == MCAMD_STEP_MAJOR) {
+                const uint64_t row = static_cast<uint64_t>(step) * a.n_local;
+                store_row<T, V, VEC>(a.traj + row, base, St, n_valid);
+                if (WINDOW && a.counts) store_row<int32_t, V, VEC>(a.counts + row, base, cnt, n_valid);
+            } else {
+#pragma unroll
+                for (int p = 0; p < V; ++p)
+                    if (p < n_valid) {
+                        const uint64_t idx = (base + p) * c.n_sim + step;
+                        a.traj[idx] = St[p];
+                        if (WINDOW && a.counts) a.counts[idx] = cnt[p];
+                    }
+            }
+        };
+        for (uint32_t k = 0; k < n_full; ++k) {
             Normals<T> nrm[V];
 #pragma unroll
             for (int p = 0; p < V; ++p) nrm[p].fill(m, a.seed, a.path_offset + base + p, k);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const uint32_t step = k * NB + j;
-                if (step < c.n_sim) {
+            for (int j = 0; j < NB; ++j) advance(nrm, j, k * NB + j);
+        }
+        if (rem) {
+            Normals<T> nrm[V];
 #pragma unroll
-                    for (int p = 0; p < V; ++p) {
-                        St[p] = gbm_step(St[p], nrm[p].z[j], c, m);
-                        if (WINDOW) cnt[p] += (c.B > St[p]) ? 1 : 0;
-                    }
-                    if (LAYOUT == MCAMD_STEP_MAJOR) {
-                        store_row<T, V>(a.traj + static_cast<uint64_t>(step) * a.n_local, base, St, a.vec_ok, n_valid);
-                        if (WINDOW && a.counts)
-                            store_row<int32_t, V>(a.counts + static_cast<uint64_t>(step) * a.n_local, base, cnt,
-                                                  a.vec_ok, n_valid);
-                    } else {
+            for (int p = 0; p < V; ++p) nrm[p].fill(m, a.seed, a.path_offset + base + p, n_full);
 #pragma unroll
-                        for (int p = 0; p < V; ++p)
-                            if (p < n_valid) {
-                                const uint64_t idx = (base + p) * c.n_sim + step;
-                                a.traj[idx] = St[p];
-                                if (WINDOW && a.counts) a.counts[idx] = cnt[p];
-                            }
-                    }
-                }
-            }
+            for (int j = 0; j < NB - 1; ++j)
+                if (static_cast<uint32_t>(j) < rem) advance(nrm, j, n_full * NB + j);
         }
 #pragma unroll
         for (int p = 0; p < V; ++p)
@@ -144,17 +153,21 @@ static hipError_t launch_store_t(const PathJob &j, int layout, void *d_traj, int
     a.vec_ok = (j.n_local % V == 0) && (reinterpret_cast<uintptr_t>(d_traj) % 16 == 0) &&
                (d_counts == nullptr || reinterpret_cast<uintptr_t>(d_counts) % 16 == 0);
     const dim3 g(grid), b(kBlock);
+#define MCAMD_LAUNCH_STORE(W, L, VEC) \
+    hipLaunchKernelGGL((store_kernel<T, W, L, VEC>), g, b, 0, stream, a, d_partials)
     if (layout == MCAMD_STEP_MAJOR) {
-        if (j.window)
-            hipLaunchKernelGGL((store_kernel<T, true, MCAMD_STEP_MAJOR>), g, b, 0, stream, a, d_partials);
-        else
-            hipLaunchKernelGGL((store_kernel<T, false, MCAMD_STEP_MAJOR>), g, b, 0, stream, a, d_partials);
+        if (a.vec_ok) {
+            if (j.window) MCAMD_LAUNCH_STORE(true, MCAMD_STEP_MAJOR, true);
+            else MCAMD_LAUNCH_STORE(false, MCAMD_STEP_MAJOR, true);
+        } else {
+            if (j.window) MCAMD_LAUNCH_STORE(true, MCAMD_STEP_MAJOR, false);
+            else MCAMD_LAUNCH_STORE(false, MCAMD_STEP_MAJOR, false);
+        }
     } else {
-        if (j.window)
-            hipLaunchKernelGGL((store_kernel<T, true, MCAMD_PATH_MAJOR>), g, b, 0, stream, a, d_partials);
-        else
-            hipLaunchKernelGGL((store_kernel<T, false, MCAMD_PATH_MAJOR>), g, b, 0, stream, a, d_partials);
+        if (j.window) MCAMD_LAUNCH_STORE(true, MCAMD_PATH_MAJOR, false);
+        else MCAMD_LAUNCH_STORE(false, MCAMD_PATH_MAJOR, false);
     }
+#undef MCAMD_LAUNCH_STORE
     return hipGetLastError();
 }
 

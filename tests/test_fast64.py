@@ -1,0 +1,30 @@
+"""CPU unit test of the hand-written fp64 math the kernels use (csrc/fast64.hpp): the header also
+compiles with plain g++, so its accuracy is pinned against long-double libm without a GPU."""
+import json
+import os
+import subprocess
+
+from conftest import ROOT
+
+
+def test_fast64_accuracy_against_long_double_libm(tmp_path):
+    exe = tmp_path / "f64check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off",
+                           "-I" + os.path.join(ROOT, "monte-carlo-project-cuda_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host_fast64_check.cpp"), "-o", str(exe)])
+    r = json.loads(subprocess.check_output([str(exe), "2000000"]))
+    assert r["uniform_mismatch"] == 0          # u and the angle are bit-identical to rocRAND's construction
+    assert r["neg2log_ulp"] <= 2.0
+    assert r["sqrt_ulp"] <= 1.0
+    assert r["sin_abs"] <= 2.5e-16 and r["cos_abs"] <= 2.5e-16
+    assert r["mul_exp_ulp"] <= 2.5
+
+
+def test_tables_are_reproducible_from_the_generator():
+    # the committed tables are what tools/gen_tables64.py writes (needs mpmath; skip without it)
+    import pytest
+    pytest.importorskip("mpmath")
+    inc = os.path.join(ROOT, "monte-carlo-project-cuda_amd", "csrc", "tables64.inc")
+    before = open(inc).read()
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_tables64.py")], stdout=subprocess.DEVNULL)
+    assert open(inc).read() == before

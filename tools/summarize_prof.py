@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Digests gpurun_out/prof_<tag>/ (written by tools/profile.sh) into profiles/<tag>_*.csv|json:
+the rocprofv3 --stats kernel summary as is, and per-kernel averages of every PMC counter."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    for key in ("price_kernel<double, false>", "price_kernel<float, false>", "store_kernel<float, false, 0, true>",
+                "final_reduce_kernel"):
+        if key in name:
+            return key
+    return name[:60]
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    for f in glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+    agg = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    out = {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"dispatches": max(len(v) for v in cs.values())}
+           for k, cs in agg.items() if "mcamd" in k or "kernel<" in k}
+    with open(os.path.join(dst, f"{tag}_pmc_per_kernel.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

@@ -280,6 +280,18 @@ def main():
         except Exception as e:  # the headline must survive a failure of the side measurement
             line["roofline_store"] = {"error": str(e)}
 
+    # opt-in log-space stepping (MCAMD_FLAG_LOG_SPACE): same draws, ln(St/S0) carried instead of St.  Reported
+    # beside the headline, never as the headline (the headline is the reference's recurrence as written).
+    if world == 1 and wl == "european252":
+        ks = []
+        for i in range(4):
+            rl = ctx.price_paths(opt, capi.make_sim(n_total, n_steps, prec, 1234 + i, lo, per_gpu, flags=capi.FLAG_LOG_SPACE))
+            ks.append(rl.kernel_ms)
+        kms = sum(ks[1:]) / len(ks[1:])
+        line["log_space_mode"] = {"kernel_ms": kms, "paths_per_s_kernel": per_gpu / (kms / 1e3), "price": rl.price,
+                                  "std_err": rl.std_err, "abs_err_vs_bs": abs(rl.price - BS_EXACT),
+                                  "valu_slots_per_path_step": W_SLOTS.get("price_f64_logspace")}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line.update(cpu_baseline(n_steps, args.cpu_sample_paths))
 

@@ -57,6 +57,12 @@ extern "C" {
 #define MCAMD_NMC_WAVE_PER_POINT 0  /* replaces compute_nmc_optimal, inc/nmc.cuh:280-386 */
 #define MCAMD_NMC_BLOCK_PER_POINT 1 /* replaces compute_nmc_one_block_per_point, inc/nmc.cuh:12-108 */
 
+/* mcamd_sim.flags */
+#define MCAMD_FLAG_LOG_SPACE 1 /* opt-in: carry ln(St/S0) through the step loop instead of St (one add per step
+                                  instead of one exp; every step still draws its normal).  Same scheme, rounding
+                                  differs at ~1e-14 relative (fp64).  Honoured by mcamd_price_paths and
+                                  mcamd_nmc_inner; the store / array-driven kernels need St itself and ignore it. */
+
 /* reduce variants: names follow the reference's ReductionType (inc/testing.cuh:100-106) */
 #define MCAMD_REDUCE_SEQUENTIAL 3
 #define MCAMD_REDUCE_FIRST_ADD 4
@@ -94,7 +100,7 @@ typedef struct mcamd_sim {
     uint32_t n_paths_inner; /* N_PATHS_INNER (nested MC only) */
     uint64_t seed;          /* the reference hard-codes 1234 / 1235 (inc/wrappers.cuh:41,163) */
     int32_t precision;      /* MCAMD_F32 or MCAMD_F64 */
-    int32_t flags;          /* reserved, 0 */
+    int32_t flags;          /* 0 or MCAMD_FLAG_LOG_SPACE */
 } mcamd_sim;
 
 /* Result of a pricing call. sum/sumsq/n are the shard's raw fp64 statistics (what a multi-GPU

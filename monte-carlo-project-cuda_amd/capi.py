@@ -16,6 +16,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NODEVICE, ERR_NOMEM = 0, 1, 2, 3, 4
 F32, F64 = 32, 64
 STEP_MAJOR, PATH_MAJOR = 0, 1
 NMC_WAVE_PER_POINT, NMC_BLOCK_PER_POINT = 0, 1
+FLAG_LOG_SPACE = 1
 REDUCE_SEQUENTIAL, REDUCE_FIRST_ADD, REDUCE_UNROLL_LAST, REDUCE_GRID_STRIDE = 3, 4, 5, 6
 
 # every symbol include/mcamd.h declares
@@ -120,9 +121,9 @@ def make_option(S0=100.0, T=1.0, K=100.0, r=0.1, v=0.2, B=0.0, P1=0, P2=0, use_w
 
 
 def make_sim(n_paths, n_steps=1, precision=F64, seed=1234, path_offset=0, n_paths_local=None,
-             n_paths_inner=0) -> Sim:
+             n_paths_inner=0, flags=0) -> Sim:
     return Sim(n_paths, path_offset, n_paths if n_paths_local is None else n_paths_local, n_steps, n_paths_inner,
-               seed, precision, 0)
+               seed, precision, flags)
 
 
 def _ptr(t):

@@ -79,6 +79,7 @@ int check_common(const mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim 
     if (!(opt->T > 0.0) || !(opt->v >= 0.0) || !std::isfinite(opt->S0) || !std::isfinite(opt->K) ||
         !std::isfinite(opt->r) || !std::isfinite(opt->T) || !std::isfinite(opt->v))
         return fail(MCAMD_ERR_INVALID, "option parameters must be finite with T > 0 and v >= 0");
+    if (sim->flags & ~MCAMD_FLAG_LOG_SPACE) return fail(MCAMD_ERR_INVALID, "unknown bits in flags: %d", sim->flags);
     if (sim->path_offset + sim->n_paths_local < sim->path_offset)
         return fail(MCAMD_ERR_INVALID, "path_offset + n_paths_local overflows 64 bits");
     return MCAMD_OK;
@@ -102,6 +103,7 @@ mcamd::PathJob make_job(const mcamd_option *opt, const mcamd_sim *sim)
     j.path_offset = sim->path_offset;
     j.n_local = sim->n_paths_local;
     j.window = opt->use_window != 0;
+    j.logspace = (sim->flags & MCAMD_FLAG_LOG_SPACE) != 0;
     j.precision = sim->precision;
     return j;
 }

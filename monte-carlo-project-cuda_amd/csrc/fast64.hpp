@@ -10,7 +10,7 @@
 //   neg2log(u)        -2 ln u          u in [2^-53, 1]                 11 fp64 ops
 //   sqrt_pos(a)       sqrt(a)          a >= 0 (clamped to >= 1e-300)   v_rsq_f64 + 8 fp64 ops
 //   sincos_q(q)       sin, cos(pi q/64)  q = 64 t, t in (0, 2]         16 fp64 ops
-//   mul_exp(S, x)     S * e^x          |x| < 700                       13 fp64 ops
+//   mul_exp(S, x)     S * e^x          |x| < 700                       12 fp64 ops
 // Accuracy (tests/test_fast64.py, against long-double libm on 4M random arguments each):
 // <= 2 ulp for neg2log / mul_exp, <= 1 ulp sqrt_pos, <= 2e-16 absolute for sin / cos.
 //
@@ -74,15 +74,17 @@ MC_HD double rsq_seed(double a)
 #endif
 }
 
-// (v + 1) * c_lo with v = x ^ (y << 21) the 53-bit integer rocRAND builds from two Philox words
-// (rocrand_normal.h box_muller_double); c_hi = 2^32 c_lo.  Exact: v + 1 <= 2^53.
-//   u = (v+1) 2^-53  -> c_lo = 2^-53      (Box-Muller radius uniform, in (0, 1])
-//   q = (v+1) 2^-46  -> c_lo = 2^-46      (64 x the angle uniform t = (v+1) 2^-52 in (0, 2])
-MC_HD double u53(uint32_t x, uint32_t y, double c_hi, double c_lo)
+// (v + 1) * c with v = x ^ (y << 21) the 53-bit integer rocRAND builds from two Philox words
+// (rocrand_normal.h box_muller_double).  v = hi 2^32 + lo is exact in a double (v < 2^53), and
+// fma(v, c, c) is rocRAND's own expression; with c a power of two the result is exact.
+//   u = (v+1) 2^-53  -> c = 2^-53      (Box-Muller radius uniform, in (0, 1])
+//   q = (v+1) 2^-46  -> c = 2^-46      (64 x the angle uniform t = (v+1) 2^-52 in (0, 2])
+MC_HD double u53(uint32_t x, uint32_t y, double c)
 {
     const uint32_t lo = x ^ (y << 21);
     const uint32_t hi = y >> 11;
-    return __builtin_fma(static_cast<double>(hi), c_hi, __builtin_fma(static_cast<double>(lo), c_lo, c_lo));
+    const double v = __builtin_fma(static_cast<double>(hi), 0x1p32, static_cast<double>(lo));
+    return __builtin_fma(v, c, c);
 }
 
 #include "tables64_consts.inc"
@@ -144,8 +146,10 @@ MC_HD void sincos_q(double q, const D2 *tab, double &s, double &c)
 // S * exp(x): x = (k / 128) ln 2 + r, |r| <= ln2 / 256; 2^(k/128) = 2^(k >> 7) * table[k & 127].
 MC_HD double mul_exp(double S, double x, const double *tab)
 {
-    const double kd = __builtin_rint(x * kNOverLn2);
-    const int32_t ki = static_cast<int32_t>(kd);
+    // round-to-nearest by adding 1.5 * 2^52: the integer lands in the low mantissa word (|x| < 2^20)
+    const double ks = __builtin_fma(x, kNOverLn2, 0x1.8p52);
+    const int32_t ki = static_cast<int32_t>(lo32(ks));
+    const double kd = ks - 0x1.8p52;
     double r = __builtin_fma(kd, -kLn2OverN_hi, x);
     r = __builtin_fma(kd, -kLn2OverN_lo, r);
     const double tv = tab[ki & 127];

@@ -18,6 +18,7 @@ struct PathJob {
     uint64_t path_offset;
     uint64_t n_local;
     bool window;
+    bool logspace;       // MCAMD_FLAG_LOG_SPACE (in-register and nested-MC kernels)
     int precision;       // 32 / 64
 };
 

@@ -106,8 +106,8 @@ __device__ __forceinline__ void box_muller(uint32_t x, uint32_t y, float &a, flo
 
 __device__ __forceinline__ void box_muller(const U4 &w, const MathCtx<double> &m, double &a, double &b)
 {
-    const double u = f64::u53(w.x, w.y, 0x1p-21, 0x1p-53);   // (v1 + 1) 2^-53, exact
-    const double q = f64::u53(w.z, w.w, 0x1p-14, 0x1p-46);   // 64 (v2 + 1) 2^-52, exact
+    const double u = f64::u53(w.x, w.y, 0x1p-53);   // (v1 + 1) 2^-53, exact
+    const double q = f64::u53(w.z, w.w, 0x1p-46);   // 64 (v2 + 1) 2^-52, exact
     const double s = f64::sqrt_pos(f64::neg2log(u, m.t.log_tab));
     double sn, cs;
     f64::sincos_q(q, m.t.sincos_tab, sn, cs);
@@ -155,6 +155,7 @@ struct StepConsts {
     T K;        // strike
     T B;        // barrier
     T S_start;  // S0, or Sk when restarting
+    T logB;     // ln(B / S_start) [fp32: log2], -inf when B <= 0: barrier test in log space
     int32_t P1, P2, Ik;
     uint32_t n_sim;  // steps to simulate = n_steps - Tk
 };
@@ -178,34 +179,70 @@ __device__ __forceinline__ T payoff(T St, int32_t count, const StepConsts<T> &c)
     return pay;
 }
 
+__device__ __forceinline__ float exp_of_logreturn(float S, float x, const MathCtx<float> &)
+{
+    return S * __builtin_amdgcn_exp2f(x);  // fp32 exponent constants carry log2(e)
+}
+
+__device__ __forceinline__ double exp_of_logreturn(double S, double x, const MathCtx<double> &m)
+{
+    return f64::mul_exp(S, x, m.t.exp_tab);
+}
+
 // Simulates n_sim steps of one path in registers from (St, count) on the Philox stream
 // (seed, subsequence) and returns its undiscounted payoff.  Step loop of
 // inc/trajectories.cuh:144-148 (and the inner loops inc/nmc.cuh:55-59, :335-339).
-template <typename T, bool WINDOW>
+//
+// LOGSPACE = false: the reference's recurrence as written, St *= exp(drift + vol G) every step.
+// LOGSPACE = true (opt-in, MCAMD_FLAG_LOG_SPACE): the same scheme carried in the logarithm — every
+// step still draws its normal, but the path accumulates ln(St / S_start) and exponentiates once at
+// the end; the barrier test B > St becomes ln(B / S_start) > ln(St / S_start).  Same mathematics,
+// different rounding (~1e-14 relative in fp64); one add (or add + fma + compare) per step instead
+// of an exp.
+// log_start: ln(St / c.S_start) in the exponent's units (0 when the path starts at c.S_start); only read
+// in LOGSPACE + WINDOW mode, where the barrier level is held as ln(B / c.S_start).
+__device__ __forceinline__ float log_ratio(float a, float b) { return __builtin_amdgcn_logf(a / b); }  // log2
+__device__ __forceinline__ double log_ratio(double a, double b) { return log(a / b); }
+
+template <typename T, bool WINDOW, bool LOGSPACE>
 __device__ __forceinline__ T simulate_path(const StepConsts<T> &c, const MathCtx<T> &m, uint64_t seed,
-                                           uint64_t subsequence, T St, int32_t count, uint32_t n_sim)
+                                           uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
+                                           T log_start = T(0))
 {
     constexpr int NB = Normals<T>::kPerBlock;
     const uint32_t n_full = n_sim / NB;
+    const uint32_t rem = n_sim - n_full * NB;
     Normals<T> nrm;
+    T acc = WINDOW ? log_start : T(0);  // LOGSPACE: WINDOW ? ln(St/S_start) so far : sum of the normals so far
+    auto step = [&](T G) {
+        if (LOGSPACE) {
+            if (WINDOW) {
+                acc = __builtin_fma(G, c.vol, acc + c.drift);
+                count += (c.logB > acc) ? 1 : 0;
+            } else {
+                acc += G;
+            }
+        } else {
+            St = gbm_step(St, G, c, m);
+            if (WINDOW) count += (c.B > St) ? 1 : 0;
+        }
+    };
     for (uint32_t k = 0; k < n_full; ++k) {
         nrm.fill(m, seed, subsequence, k);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            St = gbm_step(St, nrm.z[j], c, m);
-            if (WINDOW) count += (c.B > St) ? 1 : 0;
-        }
+        for (int j = 0; j < NB; ++j) step(nrm.z[j]);
     }
-    const uint32_t rem = n_sim - n_full * NB;
     if (rem) {
         nrm.fill(m, seed, subsequence, n_full);
 #pragma unroll
-        for (int j = 0; j < NB - 1; ++j) {
-            if (static_cast<uint32_t>(j) < rem) {
-                St = gbm_step(St, nrm.z[j], c, m);
-                if (WINDOW) count += (c.B > St) ? 1 : 0;
-            }
-        }
+        for (int j = 0; j < NB - 1; ++j)
+            if (static_cast<uint32_t>(j) < rem) step(nrm.z[j]);
+    }
+    if (LOGSPACE) {
+        if (WINDOW)
+            St = exp_of_logreturn(c.S_start, acc, m);
+        else
+            St = exp_of_logreturn(St, __builtin_fma(acc, c.vol, c.drift * static_cast<T>(n_sim)), m);
     }
     return payoff<T, WINDOW>(St, count, c);
 }

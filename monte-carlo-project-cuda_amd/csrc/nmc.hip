@@ -48,7 +48,7 @@ __device__ __forceinline__ uint64_t point_index(const NmcArgs<T> &a, uint64_t ta
     return LAYOUT == MCAMD_STEP_MAJOR ? task : path * a.n_steps + step;
 }
 
-template <typename T, bool WINDOW, int LAYOUT>
+template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE>
 __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *__restrict__ partials)
 {
     constexpr int kWaves = kBlock / kWave;
@@ -67,9 +67,10 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
         const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
         double acc = 0.0;
         if (!WINDOW || cnt0 <= a.c.P2) {
+            const T ls = (WINDOW && LOGSPACE) ? log_ratio(St0, a.c.S_start) : T(0);
             for (uint32_t j = lane; j < a.n_inner; j += kWave)
-                acc += static_cast<double>(
-                    simulate_path<T, WINDOW>(a.c, m, a.seed, point_id * a.n_inner + j, St0, cnt0, remaining));
+                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(a.c, m, a.seed, point_id * a.n_inner + j,
+                                                                               St0, cnt0, remaining, ls));
         }
         acc = wave_sum(acc);
         if (lane == 0) {
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
     }
 }
 
-template <typename T, bool WINDOW, int LAYOUT>
+template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE>
 __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double *__restrict__ partials)
 {
     const MathCtx<T> m = MathCtx<T>::init();
@@ -101,9 +102,10 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
         const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
         double acc = 0.0, zero = 0.0;
         if (!WINDOW || cnt0 <= a.c.P2) {
+            const T ls = (WINDOW && LOGSPACE) ? log_ratio(St0, a.c.S_start) : T(0);
             for (uint32_t j = threadIdx.x; j < a.n_inner; j += kBlock)
-                acc += static_cast<double>(
-                    simulate_path<T, WINDOW>(a.c, m, a.seed, point_id * a.n_inner + j, St0, cnt0, remaining));
+                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(a.c, m, a.seed, point_id * a.n_inner + j,
+                                                                               St0, cnt0, remaining, ls));
         }
         block_sum2<kBlock>(acc, zero);
         if (threadIdx.x == 0) {
@@ -127,12 +129,17 @@ uint32_t nmc_grid(const NmcJob &job, int variant)
 }
 
 template <typename T, bool WINDOW, int LAYOUT>
-static void launch_variant(const NmcArgs<T> &a, int variant, double *d_partials, uint32_t grid, hipStream_t stream)
+static void launch_variant(const NmcArgs<T> &a, int variant, bool logspace, double *d_partials, uint32_t grid,
+                           hipStream_t stream)
 {
-    if (variant == MCAMD_NMC_BLOCK_PER_POINT)
-        hipLaunchKernelGGL((nmc_block_kernel<T, WINDOW, LAYOUT>), dim3(grid), dim3(kBlock), 0, stream, a, d_partials);
-    else
-        hipLaunchKernelGGL((nmc_wave_kernel<T, WINDOW, LAYOUT>), dim3(grid), dim3(kBlock), 0, stream, a, d_partials);
+    const dim3 g(grid), b(kBlock);
+    if (variant == MCAMD_NMC_BLOCK_PER_POINT) {
+        if (logspace) hipLaunchKernelGGL((nmc_block_kernel<T, WINDOW, LAYOUT, true>), g, b, 0, stream, a, d_partials);
+        else hipLaunchKernelGGL((nmc_block_kernel<T, WINDOW, LAYOUT, false>), g, b, 0, stream, a, d_partials);
+    } else {
+        if (logspace) hipLaunchKernelGGL((nmc_wave_kernel<T, WINDOW, LAYOUT, true>), g, b, 0, stream, a, d_partials);
+        else hipLaunchKernelGGL((nmc_wave_kernel<T, WINDOW, LAYOUT, false>), g, b, 0, stream, a, d_partials);
+    }
 }
 
 template <typename T>
@@ -154,11 +161,11 @@ static hipError_t launch_nmc_t(const NmcJob &job, int layout, int variant, const
     a.out = static_cast<T *>(d_point_prices);
     const bool w = job.path.window;
     if (layout == MCAMD_STEP_MAJOR) {
-        if (w) launch_variant<T, true, MCAMD_STEP_MAJOR>(a, variant, d_partials, grid, stream);
-        else launch_variant<T, false, MCAMD_STEP_MAJOR>(a, variant, d_partials, grid, stream);
+        if (w) launch_variant<T, true, MCAMD_STEP_MAJOR>(a, variant, job.path.logspace, d_partials, grid, stream);
+        else launch_variant<T, false, MCAMD_STEP_MAJOR>(a, variant, job.path.logspace, d_partials, grid, stream);
     } else {
-        if (w) launch_variant<T, true, MCAMD_PATH_MAJOR>(a, variant, d_partials, grid, stream);
-        else launch_variant<T, false, MCAMD_PATH_MAJOR>(a, variant, d_partials, grid, stream);
+        if (w) launch_variant<T, true, MCAMD_PATH_MAJOR>(a, variant, job.path.logspace, d_partials, grid, stream);
+        else launch_variant<T, false, MCAMD_PATH_MAJOR>(a, variant, job.path.logspace, d_partials, grid, stream);
     }
     return hipGetLastError();
 }

@@ -2,6 +2,9 @@
 #pragma once
 
 #include "launch.hpp"
+
+#include <cmath>
+#include <limits>
 #include "mc_device.hpp"
 
 namespace mcamd {
@@ -17,6 +20,8 @@ inline StepConsts<T> make_consts(const PathJob &j)
     c.K = static_cast<T>(j.K);
     c.B = static_cast<T>(j.B);
     c.S_start = static_cast<T>(j.S_start);
+    c.logB = (j.B > 0.0 && j.S_start > 0.0) ? static_cast<T>(std::log(j.B / j.S_start) * scale)
+                                             : -std::numeric_limits<T>::infinity();
     c.P1 = j.P1;
     c.P2 = j.P2;
     c.Ik = j.Ik;

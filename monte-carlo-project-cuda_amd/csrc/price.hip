@@ -25,7 +25,7 @@ struct PriceArgs {
     uint64_t n_local;
 };
 
-template <typename T, bool WINDOW>
+template <typename T, bool WINDOW, bool LOGSPACE>
 __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *__restrict__ partials)
 {
     const MathCtx<T> m = MathCtx<T>::init();
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *_
     double s = 0.0, s2 = 0.0;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_local; i += stride) {
         const double pay = static_cast<double>(
-            simulate_path<T, WINDOW>(a.c, m, a.seed, a.path_offset + i, a.c.S_start, a.c.Ik, a.c.n_sim));
+            simulate_path<T, WINDOW, LOGSPACE>(a.c, m, a.seed, a.path_offset + i, a.c.S_start, a.c.Ik, a.c.n_sim));
         s += pay;
         s2 = __builtin_fma(pay, pay, s2);
     }
@@ -69,10 +69,14 @@ template <typename T>
 static hipError_t launch_price_t(const PathJob &j, double *d_partials, uint32_t grid, hipStream_t stream)
 {
     PriceArgs<T> a{make_consts<T>(j), j.seed, j.path_offset, j.n_local};
-    if (j.window)
-        hipLaunchKernelGGL((price_kernel<T, true>), dim3(grid), dim3(kBlock), 0, stream, a, d_partials);
-    else
-        hipLaunchKernelGGL((price_kernel<T, false>), dim3(grid), dim3(kBlock), 0, stream, a, d_partials);
+    const dim3 g(grid), b(kBlock);
+    if (j.window) {
+        if (j.logspace) hipLaunchKernelGGL((price_kernel<T, true, true>), g, b, 0, stream, a, d_partials);
+        else hipLaunchKernelGGL((price_kernel<T, true, false>), g, b, 0, stream, a, d_partials);
+    } else {
+        if (j.logspace) hipLaunchKernelGGL((price_kernel<T, false, true>), g, b, 0, stream, a, d_partials);
+        else hipLaunchKernelGGL((price_kernel<T, false, false>), g, b, 0, stream, a, d_partials);
+    }
     return hipGetLastError();
 }
 

@@ -217,6 +217,48 @@ def test_price_other_options_within_se(ctx, S0, K, T, r, v):
     assert abs(res.price - capi.bs_call_f64(S0, K, T, r, v)) <= 4 * res.std_err
 
 
+# ---------------- opt-in log-space stepping ----------------
+@pytest.mark.parametrize("prec", [capi.F32, capi.F64])
+@pytest.mark.parametrize("window", [0, 1])
+@pytest.mark.parametrize("n_paths,n_steps", [(1, 1), (1000, 3), (20_000, 100), (5000, 253)])
+def test_log_space_mode_vs_oracle(ctx, oracle, prec, window, n_paths, n_steps):
+    # MCAMD_FLAG_LOG_SPACE carries ln(St/S0) instead of St: same draws, same scheme, rounding differs
+    opt = capi.make_option(**BENCH, B=120.0, P1=10 if n_steps >= 100 else 0, P2=50 if n_steps >= 100 else n_steps,
+                           use_window=window)
+    sim = capi.make_sim(n_paths, n_steps, prec, seed=77, flags=capi.FLAG_LOG_SPACE)
+    res = ctx.price_paths(opt, sim)
+    plain = ctx.price_paths(opt, capi.make_sim(n_paths, n_steps, prec, seed=77))
+    ref = oracle.mc_paths(oparams(oracle, opt, sim), prec, 0, n_paths, threads=oracle.max_threads())
+    tol = 1e-11 if prec == capi.F64 else (2e-3 if window else 5e-5)
+    assert math.isclose(res.sum, ref["sum"], rel_tol=tol, abs_tol=1e-6)
+    assert math.isclose(res.sum, plain.sum, rel_tol=tol, abs_tol=1e-6)
+    assert math.isclose(res.sumsq, plain.sumsq, rel_tol=2 * tol, abs_tol=1e-6)
+
+
+def test_log_space_restart_and_price(ctx, oracle):
+    opt = capi.make_option(**BENCH, B=120.0, P1=5, P2=60, use_window=1, Ik=4, Sk=93.5, Tk=37)
+    sim = capi.make_sim(10_000, 100, capi.F64, seed=5, flags=capi.FLAG_LOG_SPACE)
+    res = ctx.price_paths(opt, sim)
+    ref = oracle.mc_paths(oparams(oracle, opt, sim), capi.F64, 0, sim.n_paths, threads=oracle.max_threads())
+    assert math.isclose(res.sum, ref["sum"], rel_tol=1e-11)
+    big = ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(4_000_000, 252, capi.F64, flags=capi.FLAG_LOG_SPACE))
+    assert abs(big.price - BS) <= 4 * big.std_err
+    with pytest.raises(capi.McamdError):
+        ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(10, 2, capi.F64, flags=8))
+
+
+def test_log_space_nmc_matches_plain(ctx):
+    n_paths, n_steps, n_inner = 32, 10, 200
+    opt = capi.make_option(**BENCH, B=105.0, P1=1, P2=7, use_window=1)
+    traj, cnt = dev(n_paths * n_steps, torch.float64), dev(n_paths * n_steps, torch.int32)
+    ctx.simulate_trajectories(opt, capi.make_sim(n_paths, n_steps, capi.F64, seed=1234), traj, cnt)
+    a, b = dev(n_paths * n_steps, torch.float64), dev(n_paths * n_steps, torch.float64)
+    ctx.nmc_inner(opt, capi.make_sim(n_paths, n_steps, capi.F64, seed=1235, n_paths_inner=n_inner), traj, cnt, a)
+    ctx.nmc_inner(opt, capi.make_sim(n_paths, n_steps, capi.F64, seed=1235, n_paths_inner=n_inner,
+                                     flags=capi.FLAG_LOG_SPACE), traj, cnt, b)
+    assert torch.allclose(a, b, rtol=1e-11, atol=1e-12)
+
+
 # ---------------- trajectory store ----------------
 @pytest.mark.parametrize("prec", [capi.F32, capi.F64])
 @pytest.mark.parametrize("n_paths,n_steps", [(1, 1), (3, 5), (4, 4), (1000, 17), (1027, 30), (4096, 252)])

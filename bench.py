@@ -134,7 +134,7 @@ def main():
     prec = capi.F32 if wl in ("european252_f32", "store") else capi.F64
     n_steps = 1 if wl == "vanilla1" else 252
     default_paths = {"european252": 10_000_000, "european252_f32": 10_000_000, "vanilla1": 100_000_000,
-                     "store": 100_000_000, "nmc": 2048}
+                     "store": 100_000_000, "nmc": 65_536}
     sharding = pkg.sharding
     if args.global_paths:
         n_total = args.global_paths

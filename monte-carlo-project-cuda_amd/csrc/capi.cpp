@@ -308,7 +308,7 @@ int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *
     if (sim->n_paths_local == 0) return MCAMD_OK;  // empty shard: all-zero statistics
     HIP_TRY(hipSetDevice(ctx->device));
     const mcamd::PathJob job = make_job(opt, sim);
-    const uint32_t grid = mcamd::price_grid(job.n_local);
+    const uint32_t grid = mcamd::price_grid(job.n_local, job.n_sim);
     if (int rc = ensure_partials(ctx, grid)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(mcamd::launch_price(job, ctx->d_partials, grid, ctx->stream));

@@ -25,7 +25,7 @@ struct PathJob {
 constexpr uint32_t kMaxGrid = 1u << 20;  // blocks; beyond this the kernels grid-stride
 
 // number of (sum, sumsq) partial pairs a launch with this many local paths writes
-uint32_t price_grid(uint64_t n_local);
+uint32_t price_grid(uint64_t n_local, uint32_t n_sim);
 hipError_t launch_price(const PathJob &job, double *d_partials, uint32_t grid, hipStream_t stream);
 
 uint32_t store_grid(uint64_t n_local, int precision);

@@ -44,25 +44,48 @@ __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *_
     }
 }
 
-// Final pass: sums n_pairs (a, b) pairs with one block, fixed order -> deterministic.
-__global__ __launch_bounds__(kBlock) void final_reduce_kernel(const double *__restrict__ partials, uint32_t n_pairs,
-                                                             double *__restrict__ out)
+// Final pass: sums n_pairs (a, b) pairs with ONE workgroup in a fixed order -> deterministic for a
+// given launch shape.  1024 threads, 16 B loads, four independent accumulator pairs per thread so the
+// L2 latency of the single workgroup is overlapped (39k pairs: ~10 us instead of ~60 us).
+constexpr int kFinalBlock = 1024;
+
+__global__ __launch_bounds__(kFinalBlock) void final_reduce_kernel(const double *__restrict__ partials,
+                                                                  uint32_t n_pairs, double *__restrict__ out)
 {
-    double s = 0.0, s2 = 0.0;
-    for (uint32_t i = threadIdx.x; i < n_pairs; i += kBlock) {
-        s += partials[2 * i];
-        s2 += partials[2 * i + 1];
+    using D2V = double __attribute__((ext_vector_type(2)));
+    const D2V *p = reinterpret_cast<const D2V *>(partials);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    uint32_t i = threadIdx.x;
+    for (; i + 3 * kFinalBlock < n_pairs; i += 4 * kFinalBlock) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const D2V v = p[i + u * kFinalBlock];
+            s[u] += v.x;
+            s2[u] += v.y;
+        }
     }
-    block_sum2<kBlock>(s, s2);
+    for (; i < n_pairs; i += kFinalBlock) {
+        const D2V v = p[i];
+        s[0] += v.x;
+        s2[0] += v.y;
+    }
+    double a = (s[0] + s[1]) + (s[2] + s[3]);
+    double b = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+    block_sum2<kFinalBlock>(a, b);
     if (threadIdx.x == 0) {
-        out[0] = s;
-        out[1] = s2;
+        out[0] = a;
+        out[1] = b;
     }
 }
 
-uint32_t price_grid(uint64_t n_local)
+// One path per thread when a path is long (fine-grained blocks keep the tail short); for short paths
+// (few steps) a thread takes several, so that a block still carries a few thousand path-steps and the
+// partial array stays small (1-step pricer at 100M paths: 12k partial pairs instead of 390k).
+uint32_t price_grid(uint64_t n_local, uint32_t n_sim)
 {
-    return clamp_grid((n_local + kBlock - 1) / kBlock);
+    const uint64_t per_thread = n_sim >= 32 ? 1 : (32 + n_sim - 1) / n_sim;
+    const uint64_t threads = (n_local + per_thread - 1) / per_thread;
+    return clamp_grid((threads + kBlock - 1) / kBlock);
 }
 
 template <typename T>
@@ -88,7 +111,7 @@ hipError_t launch_price(const PathJob &j, double *d_partials, uint32_t grid, hip
 
 hipError_t launch_final_reduce(const double *d_partials, uint32_t n_pairs, double *d_out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(kBlock), 0, stream, d_partials, n_pairs, d_out);
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_pairs, d_out);
     return hipGetLastError();
 }
 

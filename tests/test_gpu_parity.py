@@ -401,6 +401,28 @@ def test_full_size_config2_properties(ctx):
     assert math.isclose(h1.sumsq + h2.sumsq, whole.sumsq, rel_tol=1e-12)
 
 
+def test_full_size_config4_properties(ctx):
+    # config 4: nested MC, 65 536 outer x 252 steps x 1000 inner, fp64.  European-window variant (B = 0, P1 = 0,
+    # P2 = N_STEPS: every inner path runs all its remaining steps -> 2.07e12 inner path-steps).
+    # Properties: (1) last-step points have no remaining steps: inner price == discounted stored payoff (to summation rounding);
+    # (2) tower property: the mean over outer paths of the inner prices at ANY step estimates the same
+    # unconditional price e^{-rT} E[(S_T - K)+] = Black-Scholes; (3) all prices finite and >= 0.
+    n_paths, n_steps, n_inner = 65_536, 252, 1000
+    opt = capi.make_option(**BENCH, B=0.0, P1=0, P2=n_steps, use_window=1)
+    traj, cnt = dev(n_paths * n_steps, torch.float64), dev(n_paths * n_steps, torch.int32)
+    ctx.simulate_trajectories(opt, capi.make_sim(n_paths, n_steps, capi.F64, seed=1234), traj, cnt)
+    out = dev(n_paths * n_steps, torch.float64)
+    res = ctx.nmc_inner(opt, capi.make_sim(n_paths, n_steps, capi.F64, seed=1235, n_paths_inner=n_inner), traj, cnt, out)
+    V, S = out.view(n_steps, n_paths), traj.view(n_steps, n_paths)
+    assert torch.allclose(V[-1], torch.clamp(S[-1] - 100.0, min=0.0) * math.exp(-0.1), rtol=1e-13, atol=0)
+    assert torch.isfinite(out).all() and (out >= 0).all() and res.n == n_paths * n_steps
+    se_outer = 16.109 / math.sqrt(n_paths)
+    for s_ in (0, 50, 125, 200, 251):
+        assert abs(V[s_].mean().item() - BS) < 5 * se_outer, s_
+    assert math.isclose(res.sum, out.sum().item(), rel_tol=1e-9)
+    assert res.kernel_ms > 100  # sanity: this is seconds of VALU work, not a skipped launch
+
+
 def test_full_size_config3_properties(ctx):
     # config 3: 100M paths x 252 steps fp32 stored step-major (100.8 GB).  Properties: checksum of the last row
     # equals the in-register kernel's payoff sum; each row's mean follows S0 e^{r t}; nothing non-finite.

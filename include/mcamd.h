@@ -53,7 +53,8 @@ extern "C" {
 #define MCAMD_PATH_MAJOR 1 /* a[path * n_steps + step]        — the reference's layout
                               (inc/trajectories.cuh:304-305, inc/testing.cuh:69) */
 
-/* nested-MC inner strategies; all three give the same per-point prices */
+/* nested-MC strategies; all give the same per-point prices (the third reference strategy, the fused
+ * single launch, is mcamd_nmc_fused) */
 #define MCAMD_NMC_WAVE_PER_POINT 0  /* replaces compute_nmc_optimal, inc/nmc.cuh:280-386 */
 #define MCAMD_NMC_BLOCK_PER_POINT 1 /* replaces compute_nmc_one_block_per_point, inc/nmc.cuh:12-108 */
 
@@ -196,6 +197,15 @@ int mcamd_reduce_sum(mcamd_ctx *ctx, const void *d_in, uint64_t n, int precision
  * inc/wrappers.cuh:185-189,316-321). */
 int mcamd_nmc_inner(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout, int variant,
                     const void *d_prices, const int32_t *d_counts, void *d_point_prices, mcamd_result *res);
+
+/* Nested Monte Carlo, outer + inner stage fused in ONE launch: every workgroup simulates and stores the outer
+ * paths it owns (seed = outer_seed), then prices exactly those points (inner seed = sim->seed).  d_prices /
+ * d_counts / d_point_prices are OUTPUTS here (same shapes and layout rule as above; d_counts may be NULL for
+ * use_window = 0).  Results are bit-identical to mcamd_simulate_trajectories + mcamd_nmc_inner with the same
+ * two seeds.  Replaces compute_nmc_one_block_per_point_with_outter, inc/nmc.cuh:113-275
+ * (wrapper_gpu_bullet_option_nmc_one_kernel, inc/wrappers.cuh:209-266). */
+int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, uint64_t outer_seed, int layout,
+                    void *d_prices, int32_t *d_counts, void *d_point_prices, mcamd_result *res);
 
 /* Host: discount + mean + standard error + 95% CI from (sum, sumsq, n) — after an all-reduce
  * over shards, or directly.  Fills price/std_err/ci_* (and copies sum/sumsq/n) in *res. */

@@ -51,6 +51,8 @@ inline float price(const OptionData &od, uint32_t n_steps, bool window, int prec
     return static_cast<float>(r.price);
 }
 
+constexpr int kFusedNmc = -1;  // selects mcamd_nmc_fused in nested()
+
 // Outer trajectories (seed 1234) + inner stage (seed 1235); returns the mean per-point price and, if
 // asked, the per-point array in the reference's path-major indexing [path * N_STEPS + step].
 inline float nested(const OptionData &od, int variant, std::vector<float> *points = nullptr)
@@ -74,10 +76,16 @@ inline float nested(const OptionData &od, int variant, std::vector<float> *point
     const mcamd_sim outer = to_sim(n, od.N_STEPS, 1234, MCAMD_F32);
     const mcamd_sim inner = to_sim(n, od.N_STEPS, 1235, MCAMD_F32, static_cast<uint32_t>(od.N_PATHS_INNER));
     mcamd_result r;
-    int rc = mcamd_simulate_trajectories(ctx, &o, &outer, MCAMD_STEP_MAJOR, d_prices, static_cast<int32_t *>(d_counts),
+    int rc;
+    if (variant == kFusedNmc) {
+        rc = mcamd_nmc_fused(ctx, &o, &inner, outer.seed, MCAMD_STEP_MAJOR, d_prices, static_cast<int32_t *>(d_counts),
+                             d_points, &r);
+    } else {
+        rc = mcamd_simulate_trajectories(ctx, &o, &outer, MCAMD_STEP_MAJOR, d_prices, static_cast<int32_t *>(d_counts),
                                          nullptr, &r);
-    if (!rc) rc = mcamd_nmc_inner(ctx, &o, &inner, MCAMD_STEP_MAJOR, variant, d_prices,
-                                  static_cast<const int32_t *>(d_counts), d_points, &r);
+        if (!rc) rc = mcamd_nmc_inner(ctx, &o, &inner, MCAMD_STEP_MAJOR, variant, d_prices,
+                                      static_cast<const int32_t *>(d_counts), d_points, &r);
+    }
     if (!rc && points) {
         std::vector<float> step_major(n_points);
         rc = mcamd_memcpy_to_host(ctx, step_major.data(), d_points, n_points * 4);
@@ -136,12 +144,12 @@ inline float wrapper_gpu_bullet_option_nmc_one_point_one_block(OptionData option
     return p < 0 ? p : mcamd_shim::report("Average GPU bullet option nmc one point per block : ", p);
 }
 
-// The reference fuses the outer and inner stages into one launch here.  With counter-based streams
-// the fusion changes nothing observable, so this is the block-per-point strategy again.
+// The reference fuses the outer and inner stages into one launch here; so does mcamd_nmc_fused.  With
+// counter-based streams the fusion changes no number: the result equals the two-launch strategies'.
 inline float wrapper_gpu_bullet_option_nmc_one_kernel(OptionData option_data, int /*threadsPerBlock*/,
                                                       int /*number_of_blocks*/)
 {
-    const float p = mcamd_shim::nested(option_data, MCAMD_NMC_BLOCK_PER_POINT);
+    const float p = mcamd_shim::nested(option_data, mcamd_shim::kFusedNmc);
     return p < 0 ? p : mcamd_shim::report("Average GPU bullet option nmc one kernel : ", p);
 }
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "mcamd_abi_version", "mcamd_last_error", "mcamd_device_count", "mcamd_ctx_create", "mcamd_ctx_destroy",
     "mcamd_get_device_info", "mcamd_device_malloc", "mcamd_device_free", "mcamd_memcpy_to_host",
     "mcamd_memcpy_to_device", "mcamd_price_paths", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
-    "mcamd_generate_normals", "mcamd_reduce_sum", "mcamd_nmc_inner", "mcamd_finalize", "mcamd_cnd_f32",
+    "mcamd_generate_normals", "mcamd_reduce_sum", "mcamd_nmc_inner", "mcamd_nmc_fused", "mcamd_finalize", "mcamd_cnd_f32",
     "mcamd_bs_call_f32", "mcamd_bs_call_f64",
 ]
 
@@ -95,6 +95,7 @@ def load() -> C.CDLL:
     L.mcamd_generate_normals.argtypes = [vp, u64, u64, i32, vp, C.POINTER(f32)]
     L.mcamd_reduce_sum.argtypes = [vp, vp, u64, i32, i32, C.POINTER(f64), C.POINTER(f32)]
     L.mcamd_nmc_inner.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, i32, vp, vp, vp, C.POINTER(Result)]
+    L.mcamd_nmc_fused.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), u64, i32, vp, vp, vp, C.POINTER(Result)]
     L.mcamd_finalize.argtypes = [f64, f64, u64, f64, f64, C.POINTER(Result)]
     L.mcamd_cnd_f32.argtypes = [f32]
     L.mcamd_cnd_f32.restype = f32
@@ -221,5 +222,12 @@ class Context:
                   variant=NMC_WAVE_PER_POINT) -> Result:
         res = Result()
         _check(self._L.mcamd_nmc_inner(self._h, C.byref(opt), C.byref(sim), layout, variant, _ptr(prices),
+                                       _ptr(counts), _ptr(point_prices), C.byref(res)))
+        return res
+
+    def nmc_fused(self, opt: Option, sim: Sim, outer_seed: int, prices, counts, point_prices,
+                  layout=STEP_MAJOR) -> Result:
+        res = Result()
+        _check(self._L.mcamd_nmc_fused(self._h, C.byref(opt), C.byref(sim), outer_seed, layout, _ptr(prices),
                                        _ptr(counts), _ptr(point_prices), C.byref(res)))
         return res

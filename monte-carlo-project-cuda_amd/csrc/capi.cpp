@@ -451,6 +451,39 @@ int mcamd_nmc_inner(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
     return MCAMD_OK;
 }
 
+int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, uint64_t outer_seed, int layout,
+                    void *d_prices, int32_t *d_counts, void *d_point_prices, mcamd_result *res)
+{
+    if (int rc = check_common(ctx, opt, sim, res)) return rc;
+    if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
+        return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
+    if (opt->Tk != 0) return fail(MCAMD_ERR_INVALID, "nested MC simulates outer trajectories from step 0 (Tk = 0)");
+    if (sim->n_paths_inner == 0) return fail(MCAMD_ERR_INVALID, "n_paths_inner must be >= 1");
+    zero_result(res);
+    if (sim->n_paths_local == 0) return MCAMD_OK;
+    if (!d_prices || !d_point_prices) return fail(MCAMD_ERR_INVALID, "d_prices and d_point_prices must be non-NULL");
+    if (opt->use_window && !d_counts) return fail(MCAMD_ERR_INVALID, "bullet window needs d_counts");
+    const uint64_t n_points = sim->n_paths_local * static_cast<uint64_t>(sim->n_steps);
+    if (n_points / sim->n_steps != sim->n_paths_local) return fail(MCAMD_ERR_INVALID, "point count overflows");
+    HIP_TRY(hipSetDevice(ctx->device));
+    mcamd::NmcJob job;
+    job.path = make_job(opt, sim);
+    job.n_inner = sim->n_paths_inner;
+    job.discount = std::exp(-opt->r * opt->T);
+    job.n_points = n_points;
+    const uint32_t grid = mcamd::nmc_fused_grid(job);
+    if (int rc = ensure_partials(ctx, grid)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(mcamd::launch_nmc_fused(job, outer_seed, layout, d_prices, d_counts, d_point_prices, ctx->d_partials, grid,
+                                    ctx->stream));
+    if (int rc = finish(ctx, grid, res)) return rc;
+    res->n = n_points;
+    res->price = res->sum / static_cast<double>(n_points);
+    res->grid = grid;
+    res->block = 256;
+    return MCAMD_OK;
+}
+
 int mcamd_finalize(double sum, double sumsq, uint64_t n, double r, double T, mcamd_result *res)
 {
     if (!res) return fail(MCAMD_ERR_INVALID, "res is NULL");

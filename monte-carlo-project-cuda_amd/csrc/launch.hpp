@@ -55,4 +55,8 @@ uint32_t nmc_grid(const NmcJob &job, int variant);
 hipError_t launch_nmc_inner(const NmcJob &job, int layout, int variant, const void *d_prices, const int32_t *d_counts,
                             void *d_point_prices, double *d_partials, uint32_t grid, hipStream_t stream);
 
+uint32_t nmc_fused_grid(const NmcJob &job);
+hipError_t launch_nmc_fused(const NmcJob &job, uint64_t outer_seed, int layout, void *d_prices, int32_t *d_counts,
+                            void *d_point_prices, double *d_partials, uint32_t grid, hipStream_t stream);
+
 }  // namespace mcamd

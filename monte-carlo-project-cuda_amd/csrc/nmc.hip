@@ -122,6 +122,103 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused outer + inner stage in ONE launch.  Replaces compute_nmc_one_block_per_point_with_outter
+// (inc/nmc.cuh:113-275): a workgroup first simulates and stores the outer paths it owns
+// (path = blockIdx.x + i * gridDim.x, one lane per owned path), then — after a workgroup barrier,
+// which is all that is needed because a workgroup only reads points it wrote itself — runs the
+// inner stage wave-per-point over exactly those points.  No grid-wide synchronisation, no second
+// launch.  Outer stream: (outer_seed, subsequence = global path id); inner stream as nmc_wave_kernel.
+// The stored arrays and the per-point prices are bit-identical to the two-launch route.
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE>
+__global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_t outer_seed, T *prices,
+                                                          int32_t *counts, double *__restrict__ partials)
+{
+    constexpr int kWaves = kBlock / kWave;
+    constexpr int NB = Normals<T>::kPerBlock;
+    const MathCtx<T> m = MathCtx<T>::init();
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const StepConsts<T> &c = a.c;
+    // owned paths: blockIdx.x, blockIdx.x + G, ...
+    const uint64_t n_owned = a.n_local > blockIdx.x ? (a.n_local - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+
+    // ---- phase 1: outer trajectories of the owned paths (inc/nmc.cuh:144-202) ----
+    for (uint64_t i = threadIdx.x; i < n_owned; i += kBlock) {
+        const uint64_t path = blockIdx.x + i * gridDim.x;
+        T St = c.S_start;
+        int32_t cnt = c.Ik;
+        Normals<T> nrm;
+        for (uint32_t step = 0; step < a.n_steps; ++step) {
+            if (step % NB == 0) nrm.fill(m, outer_seed, a.path_offset + path, step / NB);
+            T G = nrm.z[0];
+#pragma unroll
+            for (int j = 1; j < NB; ++j) G = (step % NB == static_cast<uint32_t>(j)) ? nrm.z[j] : G;
+            St = gbm_step(St, G, c, m);
+            if (WINDOW) cnt += (c.B > St) ? 1 : 0;
+            const uint64_t idx = LAYOUT == MCAMD_STEP_MAJOR ? static_cast<uint64_t>(step) * a.n_local + path
+                                                            : path * a.n_steps + step;
+            prices[idx] = St;
+            if (WINDOW) counts[idx] = cnt;
+        }
+    }
+    __syncthreads();  // workgroup-scope release/acquire: this workgroup reads only what it wrote
+
+    // ---- phase 2: inner stage over the owned points, one wavefront per point, long tasks first ----
+    double psum = 0.0, psumsq = 0.0;
+    const uint64_t n_tasks = n_owned * a.n_steps;
+    for (uint64_t task = wave; task < n_tasks; task += kWaves) {
+        const uint32_t step = static_cast<uint32_t>(task / n_owned);
+        const uint64_t path = blockIdx.x + (task - static_cast<uint64_t>(step) * n_owned) * gridDim.x;
+        const uint64_t idx = LAYOUT == MCAMD_STEP_MAJOR ? static_cast<uint64_t>(step) * a.n_local + path
+                                                        : path * a.n_steps + step;
+        const T St0 = prices[idx];
+        const int32_t cnt0 = WINDOW ? counts[idx] : 0;
+        const uint32_t remaining = a.n_steps - (step + 1);
+        const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
+        double acc = 0.0;
+        if (!WINDOW || cnt0 <= c.P2) {
+            const T ls = (WINDOW && LOGSPACE) ? log_ratio(St0, c.S_start) : T(0);
+            for (uint32_t j = lane; j < a.n_inner; j += kWave)
+                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, a.seed, point_id * a.n_inner + j, St0,
+                                                                               cnt0, remaining, ls));
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const double price = acc * a.scale;
+            a.out[idx] = static_cast<T>(price);
+            psum += price;
+            psumsq = __builtin_fma(price, price, psumsq);
+        }
+    }
+    block_sum2<kBlock>(psum, psumsq);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = psum;
+        partials[2 * blockIdx.x + 1] = psumsq;
+    }
+}
+
+uint32_t nmc_fused_grid(const NmcJob &job)
+{
+    // enough workgroups to fill the chip several times over, few enough that each owns whole paths
+    const uint64_t want = job.path.n_local < 8192 ? job.path.n_local : 8192;
+    return static_cast<uint32_t>(want < 1 ? 1 : want);
+}
+
+template <typename T, bool WINDOW, int LAYOUT>
+static void launch_fused_variant(const NmcArgs<T> &a, uint64_t outer_seed, bool logspace, T *prices, int32_t *counts,
+                                 double *d_partials, uint32_t grid, hipStream_t stream)
+{
+    const dim3 g(grid), b(kBlock);
+    if (logspace)
+        hipLaunchKernelGGL((nmc_fused_kernel<T, WINDOW, LAYOUT, true>), g, b, 0, stream, a, outer_seed, prices, counts,
+                           d_partials);
+    else
+        hipLaunchKernelGGL((nmc_fused_kernel<T, WINDOW, LAYOUT, false>), g, b, 0, stream, a, outer_seed, prices, counts,
+                           d_partials);
+}
+
 uint32_t nmc_grid(const NmcJob &job, int variant)
 {
     if (variant == MCAMD_NMC_BLOCK_PER_POINT) return clamp_grid(job.n_points);
@@ -143,9 +240,7 @@ static void launch_variant(const NmcArgs<T> &a, int variant, bool logspace, doub
 }
 
 template <typename T>
-static hipError_t launch_nmc_t(const NmcJob &job, int layout, int variant, const void *d_prices,
-                               const int32_t *d_counts, void *d_point_prices, double *d_partials, uint32_t grid,
-                               hipStream_t stream)
+static NmcArgs<T> make_args(const NmcJob &job, const void *d_prices, const int32_t *d_counts, void *d_point_prices)
 {
     NmcArgs<T> a;
     a.c = make_consts<T>(job.path);
@@ -159,6 +254,41 @@ static hipError_t launch_nmc_t(const NmcJob &job, int layout, int variant, const
     a.prices = static_cast<const T *>(d_prices);
     a.counts = d_counts;
     a.out = static_cast<T *>(d_point_prices);
+    return a;
+}
+
+template <typename T>
+static hipError_t launch_fused_t(const NmcJob &job, uint64_t outer_seed, int layout, void *d_prices, int32_t *d_counts,
+                                 void *d_point_prices, double *d_partials, uint32_t grid, hipStream_t stream)
+{
+    const NmcArgs<T> a = make_args<T>(job, d_prices, d_counts, d_point_prices);
+    T *pr = static_cast<T *>(d_prices);
+    const bool w = job.path.window, ls = job.path.logspace;
+    if (layout == MCAMD_STEP_MAJOR) {
+        if (w) launch_fused_variant<T, true, MCAMD_STEP_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, grid, stream);
+        else launch_fused_variant<T, false, MCAMD_STEP_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, grid, stream);
+    } else {
+        if (w) launch_fused_variant<T, true, MCAMD_PATH_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, grid, stream);
+        else launch_fused_variant<T, false, MCAMD_PATH_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, grid, stream);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_nmc_fused(const NmcJob &job, uint64_t outer_seed, int layout, void *d_prices, int32_t *d_counts,
+                            void *d_point_prices, double *d_partials, uint32_t grid, hipStream_t stream)
+{
+    return job.path.precision == 32
+               ? launch_fused_t<float>(job, outer_seed, layout, d_prices, d_counts, d_point_prices, d_partials, grid, stream)
+               : launch_fused_t<double>(job, outer_seed, layout, d_prices, d_counts, d_point_prices, d_partials, grid,
+                                        stream);
+}
+
+template <typename T>
+static hipError_t launch_nmc_t(const NmcJob &job, int layout, int variant, const void *d_prices,
+                               const int32_t *d_counts, void *d_point_prices, double *d_partials, uint32_t grid,
+                               hipStream_t stream)
+{
+    const NmcArgs<T> a = make_args<T>(job, d_prices, d_counts, d_point_prices);
     const bool w = job.path.window;
     if (layout == MCAMD_STEP_MAJOR) {
         if (w) launch_variant<T, true, MCAMD_STEP_MAJOR>(a, variant, job.path.logspace, d_partials, grid, stream);

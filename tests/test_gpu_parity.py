@@ -365,6 +365,25 @@ def test_nmc_inner_vs_oracle_bruteforce(ctx, oracle, prec, variant, layout):
     assert np.allclose(O_[-1], np.where(last_ok, np.maximum(T_[-1] - 100.0, 0), 0) * math.exp(-0.1), rtol=1e-6)
 
 
+@pytest.mark.parametrize("prec", [capi.F32, capi.F64])
+@pytest.mark.parametrize("layout", [capi.STEP_MAJOR, capi.PATH_MAJOR])
+@pytest.mark.parametrize("n_paths", [1, 5, 300, 9000])
+def test_nmc_fused_equals_two_launch_route(ctx, prec, layout, n_paths):
+    # third reference strategy (inc/nmc.cuh:113-275): one launch does outer + inner; numbers must not change
+    n_steps, n_inner = 7, 70
+    opt = capi.make_option(**BENCH, B=104.0, P1=1, P2=5, use_window=1)
+    t = TORCH_T[prec]
+    traj, cnt, out = dev(n_paths * n_steps, t), dev(n_paths * n_steps, torch.int32), dev(n_paths * n_steps, t)
+    ctx.simulate_trajectories(opt, capi.make_sim(n_paths, n_steps, prec, seed=1234), traj, cnt, None, layout)
+    inner = capi.make_sim(n_paths, n_steps, prec, seed=1235, n_paths_inner=n_inner)
+    ra = ctx.nmc_inner(opt, inner, traj, cnt, out, layout, capi.NMC_WAVE_PER_POINT)
+    traj2, cnt2, out2 = dev(n_paths * n_steps, t), dev(n_paths * n_steps, torch.int32), dev(n_paths * n_steps, t)
+    rb = ctx.nmc_fused(opt, inner, 1234, traj2, cnt2, out2, layout)
+    assert torch.equal(traj, traj2) and torch.equal(cnt, cnt2)
+    assert torch.equal(out, out2)
+    assert math.isclose(ra.sum, rb.sum, rel_tol=1e-12, abs_tol=1e-12) and rb.n == n_paths * n_steps
+
+
 def test_nmc_variants_agree_and_european_window(ctx):
     # P1=0, P2=N_STEPS, B=0: deterministic work count variant (SURVEY 8d cfg 4); both strategies agree
     n_paths, n_steps, n_inner = 64, 12, 1000

@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--global-paths", type=int, default=0,
                     help="strong scaling: total paths per step, split over the ranks by contiguous path id "
                          "(e.g. 1000000000 for BASELINE configs[4])")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
+                         "multi-rank control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-store-roofline", action="store_true")
     ap.add_argument("--no-accuracy-demo", action="store_true")
@@ -126,10 +129,15 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()   # == local_rank on a node with one GPU per rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
+    coll_device = "cuda" if args.backend == "nccl" else "cpu"
 
     wl = args.workload
     prec = capi.F32 if wl in ("european252_f32", "store") else capi.F64
@@ -146,7 +154,7 @@ def main():
         lo = rank * per_gpu
     opt = capi.make_option(**OPTION)
     stream = torch.cuda.current_stream()
-    ctx = capi.Context(local_rank, stream.cuda_stream)
+    ctx = capi.Context(device_index, stream.cuda_stream)
 
     traj = None
     nmc_bufs = None
@@ -174,7 +182,7 @@ def main():
             res = ctx.price_paths(opt, sim)
         if world > 1:
             # the one collective of the path: (sum, sumsq, n), three doubles, over RCCL/xGMI
-            s, s2, n = sharding.allreduce_stats(res.sum, res.sumsq, res.n, device="cuda")
+            s, s2, n = sharding.allreduce_stats(res.sum, res.sumsq, res.n, device=coll_device)
             fin = capi.finalize(s, s2, n, opt.r, opt.T)
         else:
             fin = res
@@ -196,7 +204,7 @@ def main():
         kernel_ms.append(res.kernel_ms)
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -217,7 +225,7 @@ def main():
                                     "store": "European call, 100M paths x 252 steps, fp32, trajectories stored step-major (BASELINE configs[2])",
                                     "nmc": "nested MC, outer paths x 252 steps x 1000 inner, fp64 (BASELINE configs[3] shape)"}[wl],
                        "paths_per_gpu": per_gpu, "n_steps": n_steps, "global_paths": n_total,
-                       "sharding": f"path-id ranges over {world} rank(s), one RCCL all-reduce of (sum,sumsq,n) per step"
+                       "sharding": f"path-id ranges over {world} rank(s), one {args.backend} all-reduce of (sum,sumsq,n) per step"
                        if world > 1 else "single GPU", "seed": "1234+step", "rng": "Philox4x32-10, subsequence = global path id"},
             "path_steps_per_s": units * n_steps / elapsed,
             "kernel_ms_avg": avg_kernel_s * 1e3,

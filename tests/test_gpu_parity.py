@@ -190,6 +190,20 @@ def test_price_paths_sharding_is_exact(ctx, oracle):
     assert math.isclose(a.sum, ref["sum"], rel_tol=1e-12)
 
 
+def test_price_paths_grid_stride_beyond_max_grid(ctx):
+    # more paths than the launch has threads (grid is capped): the grid-stride loop must cover every id once
+    n = (1 << 29) + 12_345          # 5.4e8 paths, 1 step: 32 paths per thread -> capped grid strides
+    opt = capi.make_option(**BENCH)
+    whole = ctx.price_paths(opt, capi.make_sim(n, 1, capi.F32, seed=3))
+    cut = 300_000_001
+    a = ctx.price_paths(opt, capi.make_sim(n, 1, capi.F32, seed=3, path_offset=0, n_paths_local=cut))
+    b = ctx.price_paths(opt, capi.make_sim(n, 1, capi.F32, seed=3, path_offset=cut, n_paths_local=n - cut))
+    assert whole.n == n and a.n + b.n == n
+    assert math.isclose(a.sum + b.sum, whole.sum, rel_tol=1e-12)
+    assert math.isclose(a.sumsq + b.sumsq, whole.sumsq, rel_tol=1e-12)
+    assert abs(whole.price - BS) <= 4 * whole.std_err
+
+
 def test_price_paths_empty_shard_and_errors(ctx):
     res = ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(100, 3, capi.F64, n_paths_local=0))
     assert res.sum == 0 and res.n == 0

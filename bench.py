@@ -301,6 +301,19 @@ def main():
                                   "std_err": rl.std_err, "abs_err_vs_bs": abs(rl.price - BS_EXACT),
                                   "valu_slots_per_path_step": W_SLOTS.get("price_f64_logspace")}
 
+    # opt-in variance reduction on the headline workload (antithetic pairs + S_T control variate): same
+    # kernel family, reported with its own standard error.  A sample is an antithetic PAIR (2 path evaluations).
+    if world == 1 and wl == "european252":
+        fl = capi.FLAG_ANTITHETIC | capi.FLAG_CONTROL_VARIATE
+        ks = []
+        for i in range(3):
+            rv = ctx.price_paths(opt, capi.make_sim(n_total, n_steps, prec, 1234 + i, lo, per_gpu, flags=fl))
+            ks.append(rv.kernel_ms)
+        line["variance_reduction_mode"] = {
+            "flags": "antithetic+control_variate", "samples": per_gpu, "kernel_ms": sum(ks[1:]) / 2, "price": rv.price,
+            "std_err": rv.std_err, "abs_err_vs_bs": abs(rv.price - BS_EXACT), "cv_rho": rv.cv_rho, "cv_beta": rv.cv_beta,
+            "variance_ratio_vs_plain": (fin.std_err / rv.std_err) ** 2 if rv.std_err > 0 else None}
+
     # "price within 1e-4 of closed form": the standard error must be well under 1e-4, i.e. >= ~1e11 paths for this
     # option (sigma_payoff = 16.1).  The exact one-step pricer (BASELINE configs[0]'s scheme on the GPU) does that
     # in about half a second; reported beside the headline as evidence that the estimator converges to the closed

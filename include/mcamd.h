@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MCAMD_ABI_VERSION 1
+#define MCAMD_ABI_VERSION 2
 
 /* status codes */
 #define MCAMD_OK 0
@@ -63,6 +63,12 @@ extern "C" {
                                   instead of one exp; every step still draws its normal).  Same scheme, rounding
                                   differs at ~1e-14 relative (fp64).  Honoured by mcamd_price_paths and
                                   mcamd_nmc_inner; the store / array-driven kernels need St itself and ignore it. */
+
+#define MCAMD_FLAG_ANTITHETIC 2 /* opt-in (mcamd_price_paths): a sample is the antithetic pair (G, -G) of one path's
+                                  normals; its payoff is the pair's mean; n counts pairs.  New capability. */
+#define MCAMD_FLAG_CONTROL_VARIATE 4 /* opt-in (mcamd_price_paths): S_T as control variate (E[S_T] = S e^{rT} is
+                                  known); the call also returns the three cross sums and the finalized price uses the
+                                  sample-optimal beta (mcamd_finalize_cv).  New capability. */
 
 /* reduce variants: names follow the reference's ReductionType (inc/testing.cuh:100-106) */
 #define MCAMD_REDUCE_SEQUENTIAL 3
@@ -101,7 +107,7 @@ typedef struct mcamd_sim {
     uint32_t n_paths_inner; /* N_PATHS_INNER (nested MC only) */
     uint64_t seed;          /* the reference hard-codes 1234 / 1235 (inc/wrappers.cuh:41,163) */
     int32_t precision;      /* MCAMD_F32 or MCAMD_F64 */
-    int32_t flags;          /* 0 or MCAMD_FLAG_LOG_SPACE */
+    int32_t flags;          /* OR of MCAMD_FLAG_* (0 = the reference's plain estimator) */
 } mcamd_sim;
 
 /* Result of a pricing call. sum/sumsq/n are the shard's raw fp64 statistics (what a multi-GPU
@@ -119,6 +125,12 @@ typedef struct mcamd_result {
     float total_ms;    /* HIP-event time of the whole call's device work (kernel + final reduce + D2H) */
     uint32_t grid;     /* launch shape the engine chose (threadsPerBlock / number_of_blocks of the */
     uint32_t block;    /* reference wrappers are accepted by the shim and ignored) */
+    /* control variate (MCAMD_FLAG_CONTROL_VARIATE), zero otherwise: c = S_T - E[S_T] per sample */
+    double sum_c;      /* sum of c */
+    double sum_cc;     /* sum of c^2 */
+    double sum_yc;     /* sum of payoff * c */
+    double cv_beta;    /* sample-optimal coefficient cov(y, c) / var(c) used in price */
+    double cv_rho;     /* sample correlation of payoff and control; variance shrinks by 1 - rho^2 */
 } mcamd_result;
 
 /* Device report: replaces getDeviceProperty (inc/tool.cuh:56-88) and the free/total memory
@@ -210,6 +222,12 @@ int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
 /* Host: discount + mean + standard error + 95% CI from (sum, sumsq, n) — after an all-reduce
  * over shards, or directly.  Fills price/std_err/ci_* (and copies sum/sumsq/n) in *res. */
 int mcamd_finalize(double sum, double sumsq, uint64_t n, double r, double T, mcamd_result *res);
+
+/* Host: as mcamd_finalize for a control-variate run.  sums = {sum y, sum y^2, sum c, sum c^2, sum y c} with c already
+ * centred on its known mean (what mcamd_price_paths returns in sum, sumsq, sum_c, sum_cc, sum_yc — after an
+ * all-reduce over shards, or directly): price = exp(-rT) (ybar - beta cbar), beta = cov(y,c)/var(c),
+ * std_err from the residual variance var(y)(1 - rho^2). */
+int mcamd_finalize_cv(const double sums[5], uint64_t n, double r, double T, mcamd_result *res);
 
 /* Host closed form.  _f32 restates the reference's fp32 code path operation for operation
  * (CND: inc/BlackandScholes.hpp:8-30; black_scholes_CPU: :34-43); _f64 is the exact erfc form. */

@@ -15,8 +15,9 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libmcamd.so")
-SOURCES = ["price.hip", "store.hip", "aux.hip", "nmc.hip", "capi.cpp"]
-HEADERS = ["launch.hpp", "mc_device.hpp", "path_consts.hpp", "fast64.hpp", "tables64.inc", "tables64_consts.inc"]
+SOURCES = ["price_f64.hip", "price_f32.hip", "store.hip", "aux.hip", "nmc.hip", "capi.cpp"]
+HEADERS = ["launch.hpp", "mc_device.hpp", "path_consts.hpp", "fast64.hpp", "tables64.inc", "tables64_consts.inc",
+           "price_impl.hpp"]
 ARCH = "gfx950"
 
 
@@ -51,7 +52,7 @@ def _compile(src: str, force: bool, extra) -> str:
     return obj
 
 
-def build(force: bool = False, extra_flags=(), jobs: int = 4) -> str:
+def build(force: bool = False, extra_flags=(), jobs: int = 6) -> str:
     os.makedirs(OBJ, exist_ok=True)
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, tuple(extra_flags)), SOURCES))

@@ -16,7 +16,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NODEVICE, ERR_NOMEM = 0, 1, 2, 3, 4
 F32, F64 = 32, 64
 STEP_MAJOR, PATH_MAJOR = 0, 1
 NMC_WAVE_PER_POINT, NMC_BLOCK_PER_POINT = 0, 1
-FLAG_LOG_SPACE = 1
+FLAG_LOG_SPACE, FLAG_ANTITHETIC, FLAG_CONTROL_VARIATE = 1, 2, 4
 REDUCE_SEQUENTIAL, REDUCE_FIRST_ADD, REDUCE_UNROLL_LAST, REDUCE_GRID_STRIDE = 3, 4, 5, 6
 
 # every symbol include/mcamd.h declares
@@ -24,7 +24,7 @@ EXPORTS = [
     "mcamd_abi_version", "mcamd_last_error", "mcamd_device_count", "mcamd_ctx_create", "mcamd_ctx_destroy",
     "mcamd_get_device_info", "mcamd_device_malloc", "mcamd_device_free", "mcamd_memcpy_to_host",
     "mcamd_memcpy_to_device", "mcamd_price_paths", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
-    "mcamd_generate_normals", "mcamd_reduce_sum", "mcamd_nmc_inner", "mcamd_nmc_fused", "mcamd_finalize", "mcamd_cnd_f32",
+    "mcamd_generate_normals", "mcamd_reduce_sum", "mcamd_nmc_inner", "mcamd_nmc_fused", "mcamd_finalize", "mcamd_finalize_cv", "mcamd_cnd_f32",
     "mcamd_bs_call_f32", "mcamd_bs_call_f64",
 ]
 
@@ -44,7 +44,8 @@ class Sim(C.Structure):
 class Result(C.Structure):
     _fields_ = [("sum", C.c_double), ("sumsq", C.c_double), ("n", C.c_uint64), ("price", C.c_double),
                 ("std_err", C.c_double), ("ci_lo", C.c_double), ("ci_hi", C.c_double), ("kernel_ms", C.c_float),
-                ("total_ms", C.c_float), ("grid", C.c_uint32), ("block", C.c_uint32)]
+                ("total_ms", C.c_float), ("grid", C.c_uint32), ("block", C.c_uint32), ("sum_c", C.c_double),
+                ("sum_cc", C.c_double), ("sum_yc", C.c_double), ("cv_beta", C.c_double), ("cv_rho", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -97,6 +98,7 @@ def load() -> C.CDLL:
     L.mcamd_nmc_inner.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, i32, vp, vp, vp, C.POINTER(Result)]
     L.mcamd_nmc_fused.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), u64, i32, vp, vp, vp, C.POINTER(Result)]
     L.mcamd_finalize.argtypes = [f64, f64, u64, f64, f64, C.POINTER(Result)]
+    L.mcamd_finalize_cv.argtypes = [C.POINTER(f64), u64, f64, f64, C.POINTER(Result)]
     L.mcamd_cnd_f32.argtypes = [f32]
     L.mcamd_cnd_f32.restype = f32
     L.mcamd_bs_call_f32.argtypes = [f32] * 5
@@ -139,6 +141,13 @@ def _ptr(t):
 def finalize(sum_, sumsq, n, r, T) -> Result:
     res = Result()
     _check(load().mcamd_finalize(sum_, sumsq, n, r, T, C.byref(res)))
+    return res
+
+
+def finalize_cv(sums, n, r, T) -> Result:
+    res = Result()
+    arr = (C.c_double * 5)(*sums)
+    _check(load().mcamd_finalize_cv(arr, n, r, T, C.byref(res)))
     return res
 
 

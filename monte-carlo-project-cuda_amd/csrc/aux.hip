@@ -216,6 +216,50 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(const T *__restrict__ in
     }
 }
 
+// Final pass: sums n_records records of N doubles with ONE workgroup in a fixed order -> deterministic for
+// a given launch shape.  1024 threads, four independent accumulator sets per thread so the L2 latency
+// of the single workgroup is overlapped.
+constexpr int kFinalBlock = 1024;
+
+template <int N>
+__global__ __launch_bounds__(kFinalBlock) void final_reduce_kernel(const double *__restrict__ partials,
+                                                                  uint32_t n_records, double *__restrict__ out)
+{
+    double s[4][N];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < N; ++k) s[u][k] = 0.0;
+    uint32_t i = threadIdx.x;
+    for (; i + 3 * kFinalBlock < n_records; i += 4 * kFinalBlock) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < N; ++k) s[u][k] += partials[static_cast<uint64_t>(i + u * kFinalBlock) * N + k];
+    }
+    for (; i < n_records; i += kFinalBlock)
+#pragma unroll
+        for (int k = 0; k < N; ++k) s[0][k] += partials[static_cast<uint64_t>(i) * N + k];
+    double v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = (s[0][k] + s[1][k]) + (s[2][k] + s[3][k]);
+    block_sumN<kFinalBlock, N>(v);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) out[k] = v[k];
+    }
+}
+
+hipError_t launch_final_reduce(const double *d_partials, uint32_t n_records, int record_doubles, double *d_out,
+                               hipStream_t stream)
+{
+    if (record_doubles == 5)
+        hipLaunchKernelGGL(final_reduce_kernel<5>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out);
+    else
+        hipLaunchKernelGGL(final_reduce_kernel<2>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out);
+    return hipGetLastError();
+}
+
 uint32_t reduce_grid(uint64_t n, int variant)
 {
     if (variant == MCAMD_REDUCE_GRID_STRIDE) {

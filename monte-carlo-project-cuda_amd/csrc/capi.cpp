@@ -12,7 +12,7 @@
 #include <cstring>
 #include <string>
 
-static_assert(sizeof(mcamd_option) == 80 && sizeof(mcamd_sim) == 48 && sizeof(mcamd_result) == 72 &&
+static_assert(sizeof(mcamd_option) == 80 && sizeof(mcamd_sim) == 48 && sizeof(mcamd_result) == 112 &&
                   sizeof(mcamd_device_info) == 384,
               "C ABI struct layout changed: bump MCAMD_ABI_VERSION");
 
@@ -48,22 +48,23 @@ struct mcamd_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    double *d_partials = nullptr;  // 2 doubles per block
-    uint32_t partial_capacity = 0; // in pairs
-    double *d_out = nullptr;       // 2 doubles
-    double *h_out = nullptr;       // pinned, 2 doubles
+    double *d_partials = nullptr;  // one record (2 or 5 doubles) per block
+    uint64_t partial_capacity = 0; // in doubles
+    double *d_out = nullptr;       // 8 doubles
+    double *h_out = nullptr;       // pinned, 8 doubles
 };
 
 namespace {
 
-int ensure_partials(mcamd_ctx *ctx, uint32_t pairs)
+int ensure_partials(mcamd_ctx *ctx, uint32_t records, int record_doubles = 2)
 {
-    if (pairs <= ctx->partial_capacity) return MCAMD_OK;
+    const uint64_t need = static_cast<uint64_t>(records) * record_doubles;
+    if (need <= ctx->partial_capacity) return MCAMD_OK;
     if (ctx->d_partials) HIP_TRY(hipFree(ctx->d_partials));
     ctx->d_partials = nullptr;
     ctx->partial_capacity = 0;
-    HIP_TRY(hipMalloc(&ctx->d_partials, static_cast<size_t>(pairs) * 2 * sizeof(double)));
-    ctx->partial_capacity = pairs;
+    HIP_TRY(hipMalloc(&ctx->d_partials, need * sizeof(double)));
+    ctx->partial_capacity = need;
     return MCAMD_OK;
 }
 
@@ -79,7 +80,8 @@ int check_common(const mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim 
     if (!(opt->T > 0.0) || !(opt->v >= 0.0) || !std::isfinite(opt->S0) || !std::isfinite(opt->K) ||
         !std::isfinite(opt->r) || !std::isfinite(opt->T) || !std::isfinite(opt->v))
         return fail(MCAMD_ERR_INVALID, "option parameters must be finite with T > 0 and v >= 0");
-    if (sim->flags & ~MCAMD_FLAG_LOG_SPACE) return fail(MCAMD_ERR_INVALID, "unknown bits in flags: %d", sim->flags);
+    if (sim->flags & ~(MCAMD_FLAG_LOG_SPACE | MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
+        return fail(MCAMD_ERR_INVALID, "unknown bits in flags: %d", sim->flags);
     if (sim->path_offset + sim->n_paths_local < sim->path_offset)
         return fail(MCAMD_ERR_INVALID, "path_offset + n_paths_local overflows 64 bits");
     return MCAMD_OK;
@@ -104,6 +106,9 @@ mcamd::PathJob make_job(const mcamd_option *opt, const mcamd_sim *sim)
     j.n_local = sim->n_paths_local;
     j.window = opt->use_window != 0;
     j.logspace = (sim->flags & MCAMD_FLAG_LOG_SPACE) != 0;
+    j.vr = ((sim->flags & MCAMD_FLAG_ANTITHETIC) ? 1 : 0) | ((sim->flags & MCAMD_FLAG_CONTROL_VARIATE) ? 2 : 0);
+    // E[S_T] under the simulated dynamics: S_start exp(r * remaining time)
+    j.control_mean = j.S_start * std::exp(opt->r * dt * static_cast<double>(j.n_sim));
     j.precision = sim->precision;
     return j;
 }
@@ -113,19 +118,52 @@ void zero_result(mcamd_result *res)
     std::memset(res, 0, sizeof *res);
 }
 
-// final reduce of `pairs` block partials -> host, with event timing; fills sum/sumsq + timings
-int finish(mcamd_ctx *ctx, uint32_t pairs, mcamd_result *res)
+// final reduce of the block records -> host, with event timing; fills the raw sums + timings
+int finish(mcamd_ctx *ctx, uint32_t records, mcamd_result *res, int record_doubles = 2)
 {
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-    HIP_TRY(mcamd::launch_final_reduce(ctx->d_partials, pairs, ctx->d_out, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(mcamd::launch_final_reduce(ctx->d_partials, records, record_doubles, ctx->d_out, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, record_doubles * sizeof(double), hipMemcpyDeviceToHost,
+                           ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev2, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipEventElapsedTime(&res->kernel_ms, ctx->ev0, ctx->ev1));
     HIP_TRY(hipEventElapsedTime(&res->total_ms, ctx->ev0, ctx->ev2));
     res->sum = ctx->h_out[0];
     res->sumsq = ctx->h_out[1];
+    if (record_doubles == 5) {
+        res->sum_c = ctx->h_out[2];
+        res->sum_cc = ctx->h_out[3];
+        res->sum_yc = ctx->h_out[4];
+    }
     return MCAMD_OK;
+}
+
+void finalize_cv_into(const double s[5], uint64_t n, double r, double T, mcamd_result *res)
+{
+    const double disc = std::exp(-r * T);
+    const double N = static_cast<double>(n);
+    res->sum = s[0]; res->sumsq = s[1]; res->sum_c = s[2]; res->sum_cc = s[3]; res->sum_yc = s[4];
+    res->n = n;
+    if (n < 2) {
+        res->price = n ? disc * s[0] : 0.0;
+        res->std_err = 0.0;
+        res->ci_lo = res->ci_hi = res->price;
+        return;
+    }
+    const double ybar = s[0] / N, cbar = s[2] / N;
+    const double var_y = std::fmax((s[1] - N * ybar * ybar) / (N - 1.0), 0.0);
+    const double var_c = std::fmax((s[3] - N * cbar * cbar) / (N - 1.0), 0.0);
+    const double cov = (s[4] - N * ybar * cbar) / (N - 1.0);
+    const double beta = var_c > 0.0 ? cov / var_c : 0.0;
+    const double rho = (var_c > 0.0 && var_y > 0.0) ? cov / std::sqrt(var_c * var_y) : 0.0;
+    const double var_res = std::fmax(var_y - beta * cov, 0.0);
+    res->cv_beta = beta;
+    res->cv_rho = rho;
+    res->price = disc * (ybar - beta * cbar);
+    res->std_err = disc * std::sqrt(var_res / N);
+    res->ci_lo = res->price - 1.959963984540054 * res->std_err;
+    res->ci_hi = res->price + 1.959963984540054 * res->std_err;
 }
 
 void finalize_into(double sum, double sumsq, uint64_t n, double r, double T, mcamd_result *res)
@@ -204,8 +242,8 @@ int mcamd_ctx_create(int device, void *hip_stream, mcamd_ctx **out)
     hipError_t e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_out, 2 * sizeof(double));
-    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_out, 2 * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_out, 8 * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_out, 8 * sizeof(double), hipHostMallocDefault);
     if (e != hipSuccess) {
         mcamd_ctx_destroy(ctx);
         return fail(MCAMD_ERR_HIP, "context setup: %s", hipGetErrorString(e));
@@ -308,13 +346,19 @@ int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *
     if (sim->n_paths_local == 0) return MCAMD_OK;  // empty shard: all-zero statistics
     HIP_TRY(hipSetDevice(ctx->device));
     const mcamd::PathJob job = make_job(opt, sim);
+    const int rec = (job.vr & 2) ? 5 : 2;
     const uint32_t grid = mcamd::price_grid(job.n_local, job.n_sim);
-    if (int rc = ensure_partials(ctx, grid)) return rc;
+    if (int rc = ensure_partials(ctx, grid, rec)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(mcamd::launch_price(job, ctx->d_partials, grid, ctx->stream));
-    if (int rc = finish(ctx, grid, res)) return rc;
+    if (int rc = finish(ctx, grid, res, rec)) return rc;
     const float kms = res->kernel_ms, tms = res->total_ms;
-    finalize_into(res->sum, res->sumsq, sim->n_paths_local, opt->r, opt->T, res);
+    if (rec == 5) {
+        const double sums[5] = {res->sum, res->sumsq, res->sum_c, res->sum_cc, res->sum_yc};
+        finalize_cv_into(sums, sim->n_paths_local, opt->r, opt->T, res);
+    } else {
+        finalize_into(res->sum, res->sumsq, sim->n_paths_local, opt->r, opt->T, res);
+    }
     res->kernel_ms = kms;
     res->total_ms = tms;
     res->grid = grid;
@@ -326,6 +370,8 @@ int mcamd_simulate_trajectories(mcamd_ctx *ctx, const mcamd_option *opt, const m
                                 void *d_traj, int32_t *d_counts, void *d_payoffs, mcamd_result *res)
 {
     if (int rc = check_common(ctx, opt, sim, res)) return rc;
+    if (sim->flags & (MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
+        return fail(MCAMD_ERR_INVALID, "variance-reduction flags apply to mcamd_price_paths only");
     if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
         return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
     zero_result(res);
@@ -357,6 +403,8 @@ int mcamd_price_from_normals(mcamd_ctx *ctx, const mcamd_option *opt, const mcam
                              void *d_payoffs, mcamd_result *res)
 {
     if (int rc = check_common(ctx, opt, sim, res)) return rc;
+    if (sim->flags & (MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
+        return fail(MCAMD_ERR_INVALID, "variance-reduction flags apply to mcamd_price_paths only");
     zero_result(res);
     if (sim->n_paths_local == 0) return MCAMD_OK;
     if (!d_normals) return fail(MCAMD_ERR_INVALID, "d_normals is NULL");
@@ -420,6 +468,8 @@ int mcamd_nmc_inner(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
                     const void *d_prices, const int32_t *d_counts, void *d_point_prices, mcamd_result *res)
 {
     if (int rc = check_common(ctx, opt, sim, res)) return rc;
+    if (sim->flags & (MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
+        return fail(MCAMD_ERR_INVALID, "variance-reduction flags apply to mcamd_price_paths only");
     if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
         return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
     if (variant != MCAMD_NMC_WAVE_PER_POINT && variant != MCAMD_NMC_BLOCK_PER_POINT)
@@ -455,6 +505,8 @@ int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
                     void *d_prices, int32_t *d_counts, void *d_point_prices, mcamd_result *res)
 {
     if (int rc = check_common(ctx, opt, sim, res)) return rc;
+    if (sim->flags & (MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
+        return fail(MCAMD_ERR_INVALID, "variance-reduction flags apply to mcamd_price_paths only");
     if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
         return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
     if (opt->Tk != 0) return fail(MCAMD_ERR_INVALID, "nested MC simulates outer trajectories from step 0 (Tk = 0)");
@@ -489,6 +541,14 @@ int mcamd_finalize(double sum, double sumsq, uint64_t n, double r, double T, mca
     if (!res) return fail(MCAMD_ERR_INVALID, "res is NULL");
     zero_result(res);
     finalize_into(sum, sumsq, n, r, T, res);
+    return MCAMD_OK;
+}
+
+int mcamd_finalize_cv(const double sums[5], uint64_t n, double r, double T, mcamd_result *res)
+{
+    if (!res || !sums) return fail(MCAMD_ERR_INVALID, "sums and res must be non-NULL");
+    zero_result(res);
+    finalize_cv_into(sums, n, r, T, res);
     return MCAMD_OK;
 }
 

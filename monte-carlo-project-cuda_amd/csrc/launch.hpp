@@ -19,12 +19,14 @@ struct PathJob {
     uint64_t n_local;
     bool window;
     bool logspace;       // MCAMD_FLAG_LOG_SPACE (in-register and nested-MC kernels)
+    int vr;              // variance reduction of the in-register kernel: bit 0 antithetic, bit 1 control variate
+    double control_mean; // E[S_T] for the control variate
     int precision;       // 32 / 64
 };
 
 constexpr uint32_t kMaxGrid = 1u << 20;  // blocks; beyond this the kernels grid-stride
 
-// number of (sum, sumsq) partial pairs a launch with this many local paths writes
+// number of partial records (one per block) a launch with this many local paths writes
 uint32_t price_grid(uint64_t n_local, uint32_t n_sim);
 hipError_t launch_price(const PathJob &job, double *d_partials, uint32_t grid, hipStream_t stream);
 
@@ -36,8 +38,9 @@ uint32_t array_grid(uint64_t n_local);
 hipError_t launch_from_normals(const PathJob &job, const void *d_normals, void *d_payoffs, double *d_partials,
                                uint32_t grid, hipStream_t stream);
 
-// sums n_pairs (a, b) pairs into d_out[0..1]
-hipError_t launch_final_reduce(const double *d_partials, uint32_t n_pairs, double *d_out, hipStream_t stream);
+// sums n_records records of record_doubles (2 or 5) doubles into d_out[0..record_doubles)
+hipError_t launch_final_reduce(const double *d_partials, uint32_t n_records, int record_doubles, double *d_out,
+                               hipStream_t stream);
 
 hipError_t launch_generate_normals(uint64_t seed, uint64_t n, int precision, void *d_out, hipStream_t stream);
 

@@ -204,27 +204,46 @@ __device__ __forceinline__ double exp_of_logreturn(double S, double x, const Mat
 __device__ __forceinline__ float log_ratio(float a, float b) { return __builtin_amdgcn_logf(a / b); }  // log2
 __device__ __forceinline__ double log_ratio(double a, double b) { return log(a / b); }
 
-template <typename T, bool WINDOW, bool LOGSPACE>
-__device__ __forceinline__ T simulate_path(const StepConsts<T> &c, const MathCtx<T> &m, uint64_t seed,
-                                           uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
-                                           T log_start = T(0))
+// What one sample contributes: its undiscounted payoff and the control variable S_T.  With ANTI the
+// sample is the antithetic pair (G, -G) of the same normals: both members are averaged.
+template <typename T>
+struct Sample {
+    T pay;   // payoff (mean of the pair with ANTI)
+    T ctrl;  // terminal price S_T (mean of the pair with ANTI)
+};
+
+template <typename T, bool WINDOW, bool LOGSPACE, bool ANTI>
+__device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, const MathCtx<T> &m, uint64_t seed,
+                                                     uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
+                                                     T log_start = T(0))
 {
     constexpr int NB = Normals<T>::kPerBlock;
     const uint32_t n_full = n_sim / NB;
     const uint32_t rem = n_sim - n_full * NB;
     Normals<T> nrm;
-    T acc = WINDOW ? log_start : T(0);  // LOGSPACE: WINDOW ? ln(St/S_start) so far : sum of the normals so far
+    T St2 = St;               // antithetic twin
+    int32_t count2 = count;
+    // LOGSPACE: WINDOW ? ln(St/S_start) so far : sum of the normals so far (the twin's sum is its negative)
+    T acc = WINDOW ? log_start : T(0), acc2 = acc;
     auto step = [&](T G) {
         if (LOGSPACE) {
             if (WINDOW) {
                 acc = __builtin_fma(G, c.vol, acc + c.drift);
                 count += (c.logB > acc) ? 1 : 0;
+                if (ANTI) {
+                    acc2 = __builtin_fma(-G, c.vol, acc2 + c.drift);
+                    count2 += (c.logB > acc2) ? 1 : 0;
+                }
             } else {
                 acc += G;
             }
         } else {
             St = gbm_step(St, G, c, m);
             if (WINDOW) count += (c.B > St) ? 1 : 0;
+            if (ANTI) {
+                St2 = gbm_step(St2, -G, c, m);
+                if (WINDOW) count2 += (c.B > St2) ? 1 : 0;
+            }
         }
     };
     for (uint32_t k = 0; k < n_full; ++k) {
@@ -239,12 +258,32 @@ __device__ __forceinline__ T simulate_path(const StepConsts<T> &c, const MathCtx
             if (static_cast<uint32_t>(j) < rem) step(nrm.z[j]);
     }
     if (LOGSPACE) {
-        if (WINDOW)
+        const T nd = c.drift * static_cast<T>(n_sim);
+        if (WINDOW) {
             St = exp_of_logreturn(c.S_start, acc, m);
-        else
-            St = exp_of_logreturn(St, __builtin_fma(acc, c.vol, c.drift * static_cast<T>(n_sim)), m);
+            if (ANTI) St2 = exp_of_logreturn(c.S_start, acc2, m);
+        } else {
+            const T S_in = St;
+            St = exp_of_logreturn(S_in, __builtin_fma(acc, c.vol, nd), m);
+            if (ANTI) St2 = exp_of_logreturn(S_in, __builtin_fma(-acc, c.vol, nd), m);
+        }
     }
-    return payoff<T, WINDOW>(St, count, c);
+    Sample<T> out;
+    out.pay = payoff<T, WINDOW>(St, count, c);
+    out.ctrl = St;
+    if (ANTI) {
+        out.pay = T(0.5) * (out.pay + payoff<T, WINDOW>(St2, count2, c));
+        out.ctrl = T(0.5) * (St + St2);
+    }
+    return out;
+}
+
+template <typename T, bool WINDOW, bool LOGSPACE>
+__device__ __forceinline__ T simulate_path(const StepConsts<T> &c, const MathCtx<T> &m, uint64_t seed,
+                                           uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
+                                           T log_start = T(0))
+{
+    return simulate_sample<T, WINDOW, LOGSPACE, false>(c, m, seed, subsequence, St, count, n_sim, log_start).pay;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -284,6 +323,32 @@ __device__ __forceinline__ void block_sum2(double &a, double &b)
         for (int off = kWaves / 2; off > 0; off >>= 1) {
             a += __shfl_down(a, off, kWave);
             b += __shfl_down(b, off, kWave);
+        }
+    }
+}
+
+// Sums N values over the block (same scheme as block_sum2); results valid in thread 0.
+template <int BLOCK, int N>
+__device__ __forceinline__ void block_sumN(double (&v)[N])
+{
+    constexpr int kWaves = BLOCK / kWave;
+    __shared__ double lds[N * kWaves];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+    if (kWaves == 1) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) lds[N * wave + i] = v[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            v[i] = lane < kWaves ? lds[N * lane + i] : 0.0;
+#pragma unroll
+            for (int off = kWaves / 2; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, kWave);
         }
     }
 }

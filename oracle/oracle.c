@@ -200,8 +200,9 @@ double oracle_price_from_normals_f64(const double *normals, uint64_t n_paths, ui
 /* One path in fp32.  Step loop: inc/trajectories.cuh:144-148 (GPU) and
  * inc/tool.cuh:157-166 (CPU); payoff window: inc/trajectories.cuh:149-153;
  * one-step exact form (n_steps == 1): inc/trajectories.cuh:74-76. */
-static double path_f32(const oracle_params *p, uint64_t seed, uint64_t subseq, uint32_t nsim,
-                       float St, int32_t count, double *traj, int32_t *cnts, uint64_t stride)
+static double path_f32_ex(const oracle_params *p, uint64_t seed, uint64_t subseq, uint32_t nsim,
+                          float St, int32_t count, double *traj, int32_t *cnts, uint64_t stride, float sign,
+                          double *ST_out)
 {
     const float r = (float)p->r, sigma = (float)p->v, K = (float)p->K, B = (float)p->B;
     const float dt = (float)p->T / (float)p->n_steps;
@@ -211,19 +212,27 @@ static double path_f32(const oracle_params *p, uint64_t seed, uint64_t subseq, u
     float z[4];
     for (uint32_t i = 0; i < nsim; ++i) {
         if ((i & 3u) == 0) oracle_normal4_f32(seed, subseq, i >> 2, z);
-        float G = z[i & 3u];
+        float G = sign * z[i & 3u];
         St *= expf(drift + vol * G);
         if (p->use_window && B > St) count += 1;
         if (traj) traj[(uint64_t)i * stride] = (double)St;
         if (cnts) cnts[(uint64_t)i * stride] = count;
     }
+    if (ST_out) *ST_out = (double)St;
     if (p->use_window && !(count >= p->P1 && count <= p->P2)) return 0.0;
     float pay = St - K > 0.0f ? St - K : 0.0f;
     return (double)pay;
 }
 
-static double path_f64(const oracle_params *p, uint64_t seed, uint64_t subseq, uint32_t nsim,
-                       double St, int32_t count, double *traj, int32_t *cnts, uint64_t stride)
+static double path_f32(const oracle_params *p, uint64_t seed, uint64_t subseq, uint32_t nsim,
+                       float St, int32_t count, double *traj, int32_t *cnts, uint64_t stride)
+{
+    return path_f32_ex(p, seed, subseq, nsim, St, count, traj, cnts, stride, 1.0f, NULL);
+}
+
+static double path_f64_ex(const oracle_params *p, uint64_t seed, uint64_t subseq, uint32_t nsim,
+                          double St, int32_t count, double *traj, int32_t *cnts, uint64_t stride, double sign,
+                          double *ST_out)
 {
     const double r = p->r, sigma = p->v, K = p->K, B = p->B;
     const double dt = p->T / (double)p->n_steps;
@@ -233,14 +242,21 @@ static double path_f64(const oracle_params *p, uint64_t seed, uint64_t subseq, u
     double z[2];
     for (uint32_t i = 0; i < nsim; ++i) {
         if ((i & 1u) == 0) oracle_normal2_f64(seed, subseq, i >> 1, z);
-        double G = z[i & 1u];
+        double G = sign * z[i & 1u];
         St *= exp(drift + vol * G);
         if (p->use_window && B > St) count += 1;
         if (traj) traj[(uint64_t)i * stride] = St;
         if (cnts) cnts[(uint64_t)i * stride] = count;
     }
+    if (ST_out) *ST_out = St;
     if (p->use_window && !(count >= p->P1 && count <= p->P2)) return 0.0;
     return St - K > 0.0 ? St - K : 0.0;
+}
+
+static double path_f64(const oracle_params *p, uint64_t seed, uint64_t subseq, uint32_t nsim,
+                       double St, int32_t count, double *traj, int32_t *cnts, uint64_t stride)
+{
+    return path_f64_ex(p, seed, subseq, nsim, St, count, traj, cnts, stride, 1.0, NULL);
 }
 
 void oracle_mc_paths(const oracle_params *p, int precision, uint64_t path_lo, uint64_t n_local,
@@ -268,6 +284,47 @@ void oracle_mc_paths(const oracle_params *p, int precision, uint64_t path_lo, ui
     }
     *sum = s;
     *sumsq = s2;
+}
+
+/* Variance-reduced estimator (new capability, no reference counterpart; checks the engine's opt-in
+ * MCAMD_FLAG_ANTITHETIC / MCAMD_FLAG_CONTROL_VARIATE modes).  A sample is one path or, with
+ * antithetic != 0, the pair (G, -G) of one path's normals averaged.  sums = {sum y, sum y^2, sum c,
+ * sum c^2, sum y c} with c = S_T - control_mean. */
+void oracle_mc_paths_vr(const oracle_params *p, int precision, uint64_t path_lo, uint64_t n_local, int antithetic,
+                        double control_mean, double sums[5], int threads)
+{
+    const uint32_t nsim = p->n_steps - (uint32_t)p->Tk;
+    const double S_start = (p->Sk == 0.0) ? p->S0 : p->Sk;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    (void)threads;
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel for reduction(+ : s0, s1, s2, s3, s4) num_threads(threads) schedule(static)
+#endif
+    for (int64_t i = 0; i < (int64_t)n_local; ++i) {
+        uint64_t gid = path_lo + (uint64_t)i;
+        double ST = 0.0, ST2 = 0.0, y, c;
+        if (precision == 32) {
+            y = path_f32_ex(p, p->seed, gid, nsim, (float)S_start, p->Ik, NULL, NULL, 0, 1.0f, &ST);
+            c = ST;
+            if (antithetic) {
+                double y2 = path_f32_ex(p, p->seed, gid, nsim, (float)S_start, p->Ik, NULL, NULL, 0, -1.0f, &ST2);
+                y = (double)(0.5f * ((float)y + (float)y2));
+                c = (double)(0.5f * ((float)ST + (float)ST2));
+            }
+        } else {
+            y = path_f64_ex(p, p->seed, gid, nsim, S_start, p->Ik, NULL, NULL, 0, 1.0, &ST);
+            c = ST;
+            if (antithetic) {
+                double y2 = path_f64_ex(p, p->seed, gid, nsim, S_start, p->Ik, NULL, NULL, 0, -1.0, &ST2);
+                y = 0.5 * (y + y2);
+                c = 0.5 * (ST + ST2);
+            }
+        }
+        c -= control_mean;
+        s0 += y; s1 += y * y; s2 += c; s3 += c * c; s4 += y * c;
+    }
+    sums[0] = s0; sums[1] = s1; sums[2] = s2; sums[3] = s3; sums[4] = s4;
 }
 
 /* inc/nmc.cuh:47-66 + :100-103 (one_block_per_point) and :319-343,:378-381 + inc/wrappers.cuh:318

@@ -82,6 +82,11 @@ void oracle_mc_paths(const oracle_params *p, int precision, uint64_t path_lo, ui
                      double *payoffs, double *trajectories, int32_t *counts,
                      double *sum, double *sumsq, int threads);
 
+/* Opt-in variance-reduced estimator (antithetic pairs and/or S_T control variate): five raw sums
+ * {sum y, sum y^2, sum c, sum c^2, sum y c}, c = S_T - control_mean. */
+void oracle_mc_paths_vr(const oracle_params *p, int precision, uint64_t path_lo, uint64_t n_local, int antithetic,
+                        double control_mean, double sums[5], int threads);
+
 /* Nested MC inner price of one stored point (inc/nmc.cuh:47-66,100-103):
  * n_paths_inner continuation paths of n_steps-1-step steps from (St, count), windowed payoff,
  * mean, discounted by e^{-rT}.  Stream: seed = p->seed, subsequence = point_id * n_paths_inner + j. */

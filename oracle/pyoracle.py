@@ -85,6 +85,8 @@ def lib() -> C.CDLL:
         L.oracle_mc_paths.argtypes = [C.POINTER(Params), C.c_int, u64, u64, pf64, pf64, pi32, pf64, pf64,
                                       C.c_int]
         L.oracle_mc_paths.restype = None
+        L.oracle_mc_paths_vr.argtypes = [C.POINTER(Params), C.c_int, u64, u64, C.c_int, f64, pf64, C.c_int]
+        L.oracle_mc_paths_vr.restype = None
         L.oracle_nmc_point.argtypes = [C.POINTER(Params), C.c_int, u64, u32, f64, i32]
         L.oracle_nmc_point.restype = f64
         L.oracle_finalize.argtypes = [f64, f64, u64, f64, f64, pf64, pf64, pf64, pf64]
@@ -175,6 +177,15 @@ def mc_paths(params: Params, precision: int, path_lo: int, n_local: int, want_pa
     lib().oracle_mc_paths(C.byref(params), precision, path_lo, n_local, _p(pay, C.c_double),
                           _p(traj, C.c_double), _p(cnt, C.c_int32), C.byref(s), C.byref(s2), threads)
     return {"sum": s.value, "sumsq": s2.value, "payoffs": pay, "traj": traj, "counts": cnt}
+
+
+def mc_paths_vr(params: Params, precision: int, path_lo: int, n_local: int, antithetic: bool, control_mean: float,
+                threads: int = 1) -> np.ndarray:
+    """Five raw sums {sum y, sum y^2, sum c, sum c^2, sum y c} of the variance-reduced estimator."""
+    sums = np.zeros(5, dtype=np.float64)
+    lib().oracle_mc_paths_vr(C.byref(params), precision, path_lo, n_local, int(antithetic), control_mean,
+                             _p(sums, C.c_double), threads)
+    return sums
 
 
 def nmc_point(params: Params, precision: int, point_id: int, step: int, St: float, count: int) -> float:

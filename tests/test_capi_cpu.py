@@ -29,12 +29,12 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mcamd_abi_version() == 1
+    assert lib.mcamd_abi_version() == 2
 
 
 def test_struct_layout_is_the_documented_abi():
     assert C.sizeof(capi.Option) == 80 and C.sizeof(capi.Sim) == 48
-    assert C.sizeof(capi.Result) == 72 and C.sizeof(capi.DeviceInfo) == 384
+    assert C.sizeof(capi.Result) == 112 and C.sizeof(capi.DeviceInfo) == 384
 
 
 def test_closed_form_matches_reference_golden_bitwise(lib, golden):
@@ -64,6 +64,21 @@ def test_finalize_matches_oracle(lib, oracle):
     assert math.isclose(res.std_err, math.exp(-0.1) * x.std(ddof=1) / math.sqrt(x.size), rel_tol=1e-10)
     empty = capi.finalize(0.0, 0.0, 0, 0.1, 1.0)
     assert empty.price == 0.0 and empty.std_err == 0.0 and empty.n == 0
+
+
+def test_finalize_cv_matches_numpy(lib):
+    rng = np.random.default_rng(5)
+    c = rng.normal(0.0, 20.0, size=5000)
+    y = np.maximum(0.6 * c + rng.normal(8.0, 4.0, size=5000), 0.0)
+    sums = [y.sum(), (y * y).sum(), c.sum(), (c * c).sum(), (y * c).sum()]
+    res = capi.finalize_cv(sums, y.size, 0.1, 1.0)
+    beta = np.cov(y, c, ddof=1)[0, 1] / c.var(ddof=1)
+    d = math.exp(-0.1)
+    assert math.isclose(res.cv_beta, beta, rel_tol=1e-10)
+    assert math.isclose(res.price, d * (y.mean() - beta * c.mean()), rel_tol=1e-12)
+    resid = y - beta * c
+    assert math.isclose(res.std_err, d * resid.std(ddof=1) / math.sqrt(y.size), rel_tol=1e-3)
+    assert math.isclose(res.cv_rho, np.corrcoef(y, c)[0, 1], rel_tol=1e-10)
 
 
 def test_no_gpu_means_loud_failure_not_fallback(lib):

@@ -273,6 +273,65 @@ def test_log_space_nmc_matches_plain(ctx):
     assert torch.allclose(a, b, rtol=1e-11, atol=1e-12)
 
 
+# ---------------- opt-in variance reduction ----------------
+@pytest.mark.parametrize("prec", [capi.F32, capi.F64])
+@pytest.mark.parametrize("flags", [capi.FLAG_ANTITHETIC, capi.FLAG_CONTROL_VARIATE,
+                                   capi.FLAG_ANTITHETIC | capi.FLAG_CONTROL_VARIATE])
+@pytest.mark.parametrize("n_paths,n_steps,window", [(1, 1, 0), (5000, 1, 0), (20_000, 50, 0), (20_000, 100, 1)])
+def test_variance_reduction_sums_vs_oracle(ctx, oracle, prec, flags, n_paths, n_steps, window):
+    opt = capi.make_option(**BENCH, B=120.0, P1=10, P2=50, use_window=window)
+    sim = capi.make_sim(n_paths, n_steps, prec, seed=99, flags=flags)
+    res = ctx.price_paths(opt, sim)
+    es = 100.0 * math.exp(0.1)
+    want = oracle.mc_paths_vr(oparams(oracle, opt, sim), prec, 0, n_paths, bool(flags & capi.FLAG_ANTITHETIC), es,
+                              threads=oracle.max_threads())
+    tol = 1e-10 if prec == capi.F64 else (3e-3 if window else 1e-4)
+    assert math.isclose(res.sum, want[0], rel_tol=tol, abs_tol=1e-6)
+    assert math.isclose(res.sumsq, want[1], rel_tol=2 * tol, abs_tol=1e-6)
+    if flags & capi.FLAG_CONTROL_VARIATE:
+        # centred sums cancel: compare on the scale of their terms (|c| ~ 20, n terms)
+        scale = 20.0 * n_paths
+        assert abs(res.sum_c - want[2]) <= tol * scale + 1e-6
+        assert math.isclose(res.sum_cc, want[3], rel_tol=10 * tol, abs_tol=1e-3)
+        assert abs(res.sum_yc - want[4]) <= 10 * tol * 20.0 * scale + 1e-3
+        fin = capi.finalize_cv([res.sum, res.sumsq, res.sum_c, res.sum_cc, res.sum_yc], n_paths, opt.r, opt.T)
+        assert math.isclose(fin.price, res.price, rel_tol=1e-14) and math.isclose(fin.std_err, res.std_err, rel_tol=1e-12, abs_tol=1e-300)
+    else:
+        assert res.sum_c == 0 and res.cv_beta == 0
+
+
+def test_variance_reduction_shrinks_the_error(ctx):
+    # SURVEY fact 4 / BASELINE.md: antithetic ~x2.7, S_T control variate rho ~0.95 (~x10) on the benchmark option
+    n = 4_000_000
+    opt = capi.make_option(**BENCH)
+    plain = ctx.price_paths(opt, capi.make_sim(n, 16, capi.F64, seed=7))
+    anti = ctx.price_paths(opt, capi.make_sim(n, 16, capi.F64, seed=7, flags=capi.FLAG_ANTITHETIC))
+    cv = ctx.price_paths(opt, capi.make_sim(n, 16, capi.F64, seed=7, flags=capi.FLAG_CONTROL_VARIATE))
+    both = ctx.price_paths(opt, capi.make_sim(n, 16, capi.F64, seed=7, flags=capi.FLAG_ANTITHETIC | capi.FLAG_CONTROL_VARIATE))
+    for r in (plain, anti, cv, both):
+        assert abs(r.price - BS) <= 4.5 * r.std_err
+    # per SAMPLE (= antithetic pair, two path evaluations): 2 x 2.72 from BASELINE.md's per-evaluation figure
+    assert 4.5 < (plain.std_err / anti.std_err) ** 2 < 6.5
+    assert 0.94 < cv.cv_rho < 0.96 and 8.0 < (plain.std_err / cv.std_err) ** 2 < 13.0
+    assert both.std_err < cv.std_err and both.std_err < anti.std_err
+    # the flags are refused where they have no meaning
+    buf = dev(16, torch.float64)
+    with pytest.raises(capi.McamdError):
+        ctx.simulate_trajectories(opt, capi.make_sim(4, 4, capi.F64, flags=capi.FLAG_ANTITHETIC), buf)
+
+
+def test_variance_reduction_sharding(ctx):
+    opt = capi.make_option(**BENCH)
+    f = capi.FLAG_ANTITHETIC | capi.FLAG_CONTROL_VARIATE
+    n = 300_001
+    whole = ctx.price_paths(opt, capi.make_sim(n, 9, capi.F64, seed=5, flags=f))
+    a = ctx.price_paths(opt, capi.make_sim(n, 9, capi.F64, seed=5, flags=f, path_offset=0, n_paths_local=100_000))
+    b = ctx.price_paths(opt, capi.make_sim(n, 9, capi.F64, seed=5, flags=f, path_offset=100_000, n_paths_local=n - 100_000))
+    sums = [getattr(a, k) + getattr(b, k) for k in ("sum", "sumsq", "sum_c", "sum_cc", "sum_yc")]
+    fin = capi.finalize_cv(sums, n, opt.r, opt.T)
+    assert math.isclose(fin.price, whole.price, rel_tol=1e-11) and math.isclose(fin.std_err, whole.std_err, rel_tol=1e-8)
+
+
 # ---------------- trajectory store ----------------
 @pytest.mark.parametrize("prec", [capi.F32, capi.F64])
 @pytest.mark.parametrize("n_paths,n_steps", [(1, 1), (3, 5), (4, 4), (1000, 17), (1027, 30), (4096, 252)])

@@ -74,6 +74,23 @@ def load_w_slots():
             W_SLOTS.update(json.load(f))
 
 
+def pmc_traffic_bytes(kernel_key: str):
+    """HBM bytes per launch of a kernel from the committed PMC digest (profiles/*_pmc_per_kernel.json, produced by
+    tools/profile.sh: separate WRITE_SIZE and FETCH_SIZE passes over this same command).  WRITE_SIZE is in KB and
+    exact for 16 B-per-lane stores; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128 B requests at
+    64 B).  None when no digest has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    for k, v in d.items():
+        if kernel_key in k and "WRITE_SIZE" in v and "FETCH_SIZE" in v:
+            return (v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024.0
+    return None
+
+
 def cpu_baseline(n_steps: int, sample_paths: int):
     """Times the CPU path on this host: reference build if present, else the oracle port."""
     from oracle import pyoracle as o
@@ -245,14 +262,15 @@ def main():
             bytes_per_launch = per_gpu * n_steps * 4 + 16 * res.grid
             ach = bytes_per_launch / avg_kernel_s / 1e9
             line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                                "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic_bytes("store_kernel<float"),
                                 "kernel": "store_kernel<float,false,STEP_MAJOR,vec>",
                                 "algorithmic_bytes_per_launch": bytes_per_launch}
         elif wl in ("european252", "european252_f32"):
             key = "price_f64" if prec == capi.F64 else "price_f32"
             w = W_SLOTS.get(key)
             steps_per_s = per_gpu * n_steps / avg_kernel_s
-            rl = {"bound": "valu", "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s", "traffic": None,
+            rl = {"bound": "valu", "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
+                  "traffic": pmc_traffic_bytes("price_kernel<double" if prec == capi.F64 else "price_kernel<float"),
                   "kernel": f"price_kernel<{'double' if prec == capi.F64 else 'float'},false>",
                   "path_steps_per_s_kernel": steps_per_s, "valu_slots_per_path_step": w}
             if w:
@@ -281,7 +299,7 @@ def main():
                 ach = nbytes / (kms / 1e3) / 1e9
                 line["roofline_store"] = {
                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                    "traffic": None, "kernel": "store_kernel<float,false,STEP_MAJOR,vec>", "kernel_ms": kms,
+                    "traffic": pmc_traffic_bytes("store_kernel<float"), "kernel": "store_kernel<float,false,STEP_MAJOR,vec>", "kernel_ms": kms,
                     "workload": "BASELINE configs[2]: 100M paths x 252 steps fp32 stored step-major",
                     "algorithmic_bytes_per_launch": nbytes, "paths_per_s": n3 / (kms / 1e3),
                     "price": r3.price, "std_err": r3.std_err, "abs_err_vs_bs": abs(r3.price - BS_EXACT)}

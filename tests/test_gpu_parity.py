@@ -33,6 +33,9 @@ TORCH_T = {capi.F64: torch.float64, capi.F32: torch.float32}
 @pytest.fixture(scope="module")
 def ctx():
     assert torch.cuda.is_available(), "GPU tests need a GPU; there is no CPU fallback"
+    import os
+    if not os.path.exists(capi.LIB_PATH):   # a box that received sources only: build the HIP library first
+        pkg.build()
     torch.cuda.set_device(0)
     c = capi.Context(0, torch.cuda.current_stream().cuda_stream)
     yield c

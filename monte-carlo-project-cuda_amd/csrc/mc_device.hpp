@@ -57,7 +57,7 @@ __device__ __forceinline__ U4 philox_block(uint64_t seed, uint64_t subsequence, 
 
 // ---------------------------------------------------------------------------------------------
 // Per-workgroup math context.  The fp64 path uses the table-driven functions of fast64.hpp; their
-// three 128-entry tables (5 KB) are copied into LDS once per workgroup, so the per-lane lookups
+// three 512-entry tables (20 KB) are copied into LDS once per workgroup, so the per-lane lookups
 // run on the LDS pipe beside the VALU.  The fp32 path needs nothing (hardware transcendentals).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -107,7 +107,7 @@ __device__ __forceinline__ void box_muller(uint32_t x, uint32_t y, float &a, flo
 __device__ __forceinline__ void box_muller(const U4 &w, const MathCtx<double> &m, double &a, double &b)
 {
     const double u = f64::u53(w.x, w.y, 0x1p-53);   // (v1 + 1) 2^-53, exact
-    const double q = f64::u53(w.z, w.w, 0x1p-46);   // 64 (v2 + 1) 2^-52, exact
+    const double q = f64::u53(w.z, w.w, 0x1p-44);   // 256 (v2 + 1) 2^-52, exact
     const double s = f64::sqrt_pos(f64::neg2log(u, m.t.log_tab));
     double sn, cs;
     f64::sincos_q(q, m.t.sincos_tab, sn, cs);

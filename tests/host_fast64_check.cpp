@@ -47,10 +47,10 @@ int main(int argc, char **argv)
         else { const double e = ulp_err(aa, want_a); if (e > e_log) e_log = e; }
         const double s = sqrt_pos(std::fmax(aa, 0.0));
         if (aa > 0) { const double e = ulp_err(s, sqrtl(static_cast<long double>(aa))); if (e > e_sqrt) e_sqrt = e; }
-        const double q = u53(z, w, 0x1p-46);
+        const double q = u53(z, w, 0x1p-44);
         const uint64_t v2 = static_cast<uint64_t>(z) ^ (static_cast<uint64_t>(w) << 21);
         const double t_ref = std::fma(static_cast<double>(v2), 0x1p-52, 0x1p-52);
-        if (q != 64.0 * t_ref) e_u = 2;
+        if (q != 256.0 * t_ref) e_u = 2;
         double sn, cs;
         sincos_q(q, T.sincos_tab, sn, cs);
         const long double ang = PI * static_cast<long double>(t_ref);

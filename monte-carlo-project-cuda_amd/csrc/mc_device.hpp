@@ -152,6 +152,7 @@ template <typename T>
 struct StepConsts {
     T drift;    // (r - v^2/2) dt          [fp32: times log2 e]
     T vol;      // v sqrt(dt)              [fp32: times log2 e]
+    T vol_bm;   // fp32: vol * sqrt(2 ln 2), so that vol * sqrt(-2 ln u) = vol_bm * sqrt(-log2 u); fp64: = vol
     T K;        // strike
     T B;        // barrier
     T S_start;  // S0, or Sk when restarting
@@ -169,6 +170,64 @@ __device__ __forceinline__ double gbm_step(double St, double G, const StepConsts
 {
     return f64::mul_exp(St, __builtin_fma(G, c.vol, c.drift), m.t.exp_tab);
 }
+
+// GBM step from a ready exponent x = drift + vol G.
+__device__ __forceinline__ float gbm_step_x(float St, float x, const MathCtx<float> &)
+{
+    return St * __builtin_amdgcn_exp2f(x);
+}
+
+__device__ __forceinline__ double gbm_step_x(double St, double x, const MathCtx<double> &m)
+{
+    return f64::mul_exp(St, x, m.t.exp_tab);
+}
+
+// Exponents of one Philox block: x[j] = drift + vol * z[j] for the block's normals z (4 fp32 / 2 fp64),
+// without materialising z: the Box-Muller radius is multiplied by vol once per pair and the constant
+// sqrt(2 ln 2) of the fp32 radius is folded into vol_bm (two multiplies fewer per pair than
+// normal-then-scale; the value differs from fma(z, vol, drift) by rounding only).
+template <typename T>
+struct Exponents;
+
+template <>
+struct Exponents<float> {
+    static constexpr int kPerBlock = 4;
+    float x[4];
+    __device__ __forceinline__ void pair(uint32_t a, uint32_t b, const StepConsts<float> &c, float &x0, float &x1)
+    {
+        constexpr float k2pow32inv = 2.3283064365386963e-10f;
+        const float u = __builtin_fmaf(static_cast<float>(a), k2pow32inv, k2pow32inv);
+        const float rev = __builtin_fmaf(static_cast<float>(b), k2pow32inv, k2pow32inv);
+        const float sv = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u)) * c.vol_bm;
+        x0 = __builtin_fmaf(__builtin_amdgcn_sinf(rev), sv, c.drift);
+        x1 = __builtin_fmaf(__builtin_amdgcn_cosf(rev), sv, c.drift);
+    }
+    __device__ __forceinline__ void fill(const MathCtx<float> &, const StepConsts<float> &c, uint64_t seed,
+                                         uint64_t subsequence, uint64_t block)
+    {
+        const U4 w = philox_block(seed, subsequence, block);
+        pair(w.x, w.y, c, x[0], x[1]);
+        pair(w.z, w.w, c, x[2], x[3]);
+    }
+};
+
+template <>
+struct Exponents<double> {
+    static constexpr int kPerBlock = 2;
+    double x[2];
+    __device__ __forceinline__ void fill(const MathCtx<double> &m, const StepConsts<double> &c, uint64_t seed,
+                                         uint64_t subsequence, uint64_t block)
+    {
+        const U4 w = philox_block(seed, subsequence, block);
+        const double u = f64::u53(w.x, w.y, 0x1p-53);
+        const double q = f64::u53(w.z, w.w, 0x1p-44);
+        const double sv = f64::sqrt_pos(f64::neg2log(u, m.t.log_tab)) * c.vol_bm;
+        double sn, cs;
+        f64::sincos_q(q, m.t.sincos_tab, sn, cs);
+        x[0] = __builtin_fma(sn, sv, c.drift);
+        x[1] = __builtin_fma(cs, sv, c.drift);
+    }
+};
 
 template <typename T, bool WINDOW>
 __device__ __forceinline__ T payoff(T St, int32_t count, const StepConsts<T> &c)
@@ -220,13 +279,13 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
     constexpr int NB = Normals<T>::kPerBlock;
     const uint32_t n_full = n_sim / NB;
     const uint32_t rem = n_sim - n_full * NB;
-    Normals<T> nrm;
     T St2 = St;               // antithetic twin
     int32_t count2 = count;
     // LOGSPACE: WINDOW ? ln(St/S_start) so far : sum of the normals so far (the twin's sum is its negative)
     T acc = WINDOW ? log_start : T(0), acc2 = acc;
-    auto step = [&](T G) {
-        if (LOGSPACE) {
+    if (LOGSPACE) {
+        Normals<T> nrm;
+        auto step = [&](T G) {
             if (WINDOW) {
                 acc = __builtin_fma(G, c.vol, acc + c.drift);
                 count += (c.logB > acc) ? 1 : 0;
@@ -237,25 +296,41 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
             } else {
                 acc += G;
             }
-        } else {
-            St = gbm_step(St, G, c, m);
+        };
+        for (uint32_t k = 0; k < n_full; ++k) {
+            nrm.fill(m, seed, subsequence, k);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) step(nrm.z[j]);
+        }
+        if (rem) {
+            nrm.fill(m, seed, subsequence, n_full);
+#pragma unroll
+            for (int j = 0; j < NB - 1; ++j)
+                if (static_cast<uint32_t>(j) < rem) step(nrm.z[j]);
+        }
+    } else {
+        // the reference's recurrence: St *= exp(drift + vol G); the twin uses drift - vol G = 2 drift - x
+        Exponents<T> ex;
+        const T two_drift = c.drift + c.drift;
+        auto step = [&](T x) {
+            St = gbm_step_x(St, x, m);
             if (WINDOW) count += (c.B > St) ? 1 : 0;
             if (ANTI) {
-                St2 = gbm_step(St2, -G, c, m);
+                St2 = gbm_step_x(St2, two_drift - x, m);
                 if (WINDOW) count2 += (c.B > St2) ? 1 : 0;
             }
+        };
+        for (uint32_t k = 0; k < n_full; ++k) {
+            ex.fill(m, c, seed, subsequence, k);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) step(ex.x[j]);
         }
-    };
-    for (uint32_t k = 0; k < n_full; ++k) {
-        nrm.fill(m, seed, subsequence, k);
+        if (rem) {
+            ex.fill(m, c, seed, subsequence, n_full);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) step(nrm.z[j]);
-    }
-    if (rem) {
-        nrm.fill(m, seed, subsequence, n_full);
-#pragma unroll
-        for (int j = 0; j < NB - 1; ++j)
-            if (static_cast<uint32_t>(j) < rem) step(nrm.z[j]);
+            for (int j = 0; j < NB - 1; ++j)
+                if (static_cast<uint32_t>(j) < rem) step(ex.x[j]);
+        }
     }
     if (LOGSPACE) {
         const T nd = c.drift * static_cast<T>(n_sim);

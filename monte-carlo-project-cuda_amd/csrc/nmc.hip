@@ -149,13 +149,13 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
         const uint64_t path = blockIdx.x + i * gridDim.x;
         T St = c.S_start;
         int32_t cnt = c.Ik;
-        Normals<T> nrm;
+        Exponents<T> ex;
         for (uint32_t step = 0; step < a.n_steps; ++step) {
-            if (step % NB == 0) nrm.fill(m, outer_seed, a.path_offset + path, step / NB);
-            T G = nrm.z[0];
+            if (step % NB == 0) ex.fill(m, c, outer_seed, a.path_offset + path, step / NB);
+            T x = ex.x[0];
 #pragma unroll
-            for (int j = 1; j < NB; ++j) G = (step % NB == static_cast<uint32_t>(j)) ? nrm.z[j] : G;
-            St = gbm_step(St, G, c, m);
+            for (int j = 1; j < NB; ++j) x = (step % NB == static_cast<uint32_t>(j)) ? ex.x[j] : x;
+            St = gbm_step_x(St, x, m);
             if (WINDOW) cnt += (c.B > St) ? 1 : 0;
             const uint64_t idx = LAYOUT == MCAMD_STEP_MAJOR ? static_cast<uint64_t>(step) * a.n_local + path
                                                             : path * a.n_steps + step;

@@ -17,6 +17,7 @@ inline StepConsts<T> make_consts(const PathJob &j)
     StepConsts<T> c;
     c.drift = static_cast<T>(j.drift * scale);
     c.vol = static_cast<T>(j.vol * scale);
+    c.vol_bm = static_cast<T>(j.vol * scale * (sizeof(T) == 4 ? 1.1774100225154747 : 1.0));  // sqrt(2 ln 2)
     c.K = static_cast<T>(j.K);
     c.B = static_cast<T>(j.B);
     c.S_start = static_cast<T>(j.S_start);

@@ -78,10 +78,10 @@ __global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *_
             St[p] = c.S_start;
             cnt[p] = c.Ik;
         }
-        auto advance = [&](const Normals<T>(&nrm)[V], int j, uint32_t step) {
+        auto advance = [&](const Exponents<T>(&nrm)[V], int j, uint32_t step) {
 #pragma unroll
             for (int p = 0; p < V; ++p) {
-                St[p] = gbm_step(St[p], nrm[p].z[j], c, m);
+                St[p] = gbm_step_x(St[p], nrm[p].x[j], m);
                 if (WINDOW) cnt[p] += (c.B > St[p]) ? 1 : 0;
             }
             if (LAYOUT == MCAMD_STEP_MAJOR) {
@@ -99,16 +99,16 @@ __global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *_
             }
         };
         for (uint32_t k = 0; k < n_full; ++k) {
-            Normals<T> nrm[V];
+            Exponents<T> nrm[V];
 #pragma unroll
-            for (int p = 0; p < V; ++p) nrm[p].fill(m, a.seed, a.path_offset + base + p, k);
+            for (int p = 0; p < V; ++p) nrm[p].fill(m, c, a.seed, a.path_offset + base + p, k);
 #pragma unroll
             for (int j = 0; j < NB; ++j) advance(nrm, j, k * NB + j);
         }
         if (rem) {
-            Normals<T> nrm[V];
+            Exponents<T> nrm[V];
 #pragma unroll
-            for (int p = 0; p < V; ++p) nrm[p].fill(m, a.seed, a.path_offset + base + p, n_full);
+            for (int p = 0; p < V; ++p) nrm[p].fill(m, c, a.seed, a.path_offset + base + p, n_full);
 #pragma unroll
             for (int j = 0; j < NB - 1; ++j)
                 if (static_cast<uint32_t>(j) < rem) advance(nrm, j, n_full * NB + j);

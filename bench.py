@@ -6,9 +6,9 @@ call (S0=K=100, T=1, r=0.1, sigma=0.2 — hello.cu:6-10) through the C ABI (mcam
 Philox RNG -> 252 GBM steps -> payoff -> fp64 (sum, sumsq), nothing stored — BASELINE.json
 configs[1] (10M paths, 252 steps, fp64, in-register) per GPU.  With N > 1 (launched by
 torch.distributed.run, one rank per GPU) the global job is N x 10M paths sharded by contiguous
-global path id, and each step ends with ONE all-reduce of (sum, sumsq, n) over RCCL; weak scaling.
-Inputs are a handful of scalars, so nothing crosses PCIe in the timed region except the 16-byte
-result of each call.
+global path id, and each step ends with ONE all-reduce of the 6-double statistics record over RCCL,
+enqueued on the same stream (mcamd_price_paths_enqueue): no host round trip per step; weak scaling.
+Inputs are a handful of scalars, so nothing crosses PCIe in the timed region.
 
 Extra objects on the line:
   roofline      the dominant kernel (price_kernel<double,false>) against the VALU issue roofline
@@ -185,20 +185,26 @@ def main():
         pp = torch.empty(per_gpu * n_steps, dtype=torch.float64, device="cuda")
         nmc_bufs = (wopt, tr, cn, pp, n_inner)
 
-    def one_step(i: int):
+    is_price = wl in ("european252", "european252_f32", "vanilla1")
+    # in-register workloads run asynchronously: each step enqueues the simulation + final reduce, then (N > 1) ONE
+    # all-reduce of the 6-double stats record on the same stream; the host synchronises once, after the K steps.
+    stats = torch.zeros(max(args.steps, 1) + args.warmup, 8, dtype=torch.float64, device="cuda")
+
+    def one_step(i: int, slot: int = 0):
         seed = 1234 + i
+        if is_price:
+            ctx.price_paths_enqueue(opt, capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu), stats[slot])
+            if world > 1:
+                dist.all_reduce(stats[slot])   # the one collective of the path: (sum, sumsq, .., n) over RCCL/xGMI
+            return None, None
         if wl == "store":
             sim = capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu)
             res = ctx.simulate_trajectories(opt, sim, traj)
-        elif wl == "nmc":
+        else:
             wopt, tr, cn, pp, n_inner = nmc_bufs
             ctx.simulate_trajectories(wopt, capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu), tr, cn)
             res = ctx.nmc_inner(wopt, capi.make_sim(n_total, n_steps, prec, seed + 1, lo, per_gpu, n_inner), tr, cn, pp)
-        else:
-            sim = capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu)
-            res = ctx.price_paths(opt, sim)
         if world > 1:
-            # the one collective of the path: (sum, sumsq, n), three doubles, over RCCL/xGMI
             s, s2, n = sharding.allreduce_stats(res.sum, res.sumsq, res.n, device=coll_device)
             fin = capi.finalize(s, s2, n, opt.r, opt.T)
         else:
@@ -211,20 +217,24 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        one_step(-1 - i)
+        one_step(-1 - i, args.steps + i)
     fence()
     t0 = time.perf_counter()
     kernel_ms = []
-    fin = None
+    fin = res = None
     for i in range(args.steps):
-        res, fin = one_step(i)
-        kernel_ms.append(res.kernel_ms)
+        res, fin = one_step(i, i)
+        if res is not None:
+            kernel_ms.append(res.kernel_ms)
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    if is_price:
+        kernel_ms = ctx.enqueued_kernel_ms(min(args.steps, 64))
+        fin = capi.finalize_stats(stats[args.steps - 1, :6].tolist(), opt.r, opt.T)
 
     line = None
     if rank == 0:
@@ -259,7 +269,7 @@ def main():
                          "within_1e-4": abs(fin.price - BS_EXACT) <= 1e-4})
         # roofline of the dominant kernel, from the library's HIP events on the launch stream
         if wl == "store":
-            bytes_per_launch = per_gpu * n_steps * 4 + 16 * res.grid
+            bytes_per_launch = per_gpu * n_steps * 4 + 16 * res.grid   # trajectories + block records
             ach = bytes_per_launch / avg_kernel_s / 1e9
             line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic_bytes("store_kernel<float"),

@@ -170,6 +170,18 @@ int mcamd_memcpy_to_device(mcamd_ctx *ctx, void *d_dst, const void *h_src, uint6
  * and is the multi-step European pricer of BASELINE configs 2 and 5 (use_window = 0). */
 int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, mcamd_result *res);
 
+/* Asynchronous form of mcamd_price_paths: enqueues the simulation kernel and the final reduction on the context's
+ * stream and returns without waiting.  d_stats (device, >= 6 doubles) receives {sum, sumsq, sum_c, sum_cc, sum_yc, n}
+ * (the cross sums are zero without MCAMD_FLAG_CONTROL_VARIATE).  The caller orders later work on the same stream —
+ * typically ONE all-reduce of d_stats over the ranks — and finalizes after synchronising (mcamd_finalize_stats), so
+ * a multi-step driver pays no host round trip per step.  New (the reference is fully synchronous). */
+int mcamd_price_paths_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, double *d_stats);
+/* HIP-event times (ms) of the simulation kernels of the last n_last (<= 64) enqueued calls, oldest first.
+ * Synchronises the stream. */
+int mcamd_enqueued_kernel_ms(mcamd_ctx *ctx, uint32_t n_last, float *ms);
+/* Host: finalize a (possibly all-reduced) 6-double stats record copied back from the device. */
+int mcamd_finalize_stats(const double stats[6], double r, double T, int control_variate, mcamd_result *res);
+
 /* Trajectory store: as above, and every St (and, if d_counts != NULL, every running barrier
  * count) is written to HBM.  d_traj: n_sim_steps * n_paths_local elements of the path precision
  * (n_sim_steps = n_steps - Tk); d_counts: same shape, int32, or NULL; d_payoffs: n_paths_local

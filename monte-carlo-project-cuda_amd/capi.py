@@ -23,7 +23,8 @@ REDUCE_SEQUENTIAL, REDUCE_FIRST_ADD, REDUCE_UNROLL_LAST, REDUCE_GRID_STRIDE = 3,
 EXPORTS = [
     "mcamd_abi_version", "mcamd_last_error", "mcamd_device_count", "mcamd_ctx_create", "mcamd_ctx_destroy",
     "mcamd_get_device_info", "mcamd_device_malloc", "mcamd_device_free", "mcamd_memcpy_to_host",
-    "mcamd_memcpy_to_device", "mcamd_price_paths", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
+    "mcamd_memcpy_to_device", "mcamd_price_paths", "mcamd_price_paths_enqueue", "mcamd_enqueued_kernel_ms",
+    "mcamd_finalize_stats", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
     "mcamd_generate_normals", "mcamd_reduce_sum", "mcamd_nmc_inner", "mcamd_nmc_fused", "mcamd_finalize", "mcamd_finalize_cv", "mcamd_cnd_f32",
     "mcamd_bs_call_f32", "mcamd_bs_call_f64",
 ]
@@ -90,6 +91,9 @@ def load() -> C.CDLL:
     L.mcamd_memcpy_to_host.argtypes = [vp, vp, vp, u64]
     L.mcamd_memcpy_to_device.argtypes = [vp, vp, vp, u64]
     L.mcamd_price_paths.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), C.POINTER(Result)]
+    L.mcamd_price_paths_enqueue.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), vp]
+    L.mcamd_enqueued_kernel_ms.argtypes = [vp, C.c_uint32, C.POINTER(f32)]
+    L.mcamd_finalize_stats.argtypes = [C.POINTER(f64), f64, f64, i32, C.POINTER(Result)]
     L.mcamd_simulate_trajectories.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, vp, vp, vp,
                                               C.POINTER(Result)]
     L.mcamd_price_from_normals.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), vp, vp, C.POINTER(Result)]
@@ -151,6 +155,13 @@ def finalize_cv(sums, n, r, T) -> Result:
     return res
 
 
+def finalize_stats(stats6, r, T, control_variate=False) -> Result:
+    res = Result()
+    arr = (C.c_double * 6)(*[float(x) for x in stats6])
+    _check(load().mcamd_finalize_stats(arr, r, T, int(control_variate), C.byref(res)))
+    return res
+
+
 def cnd_f32(x):
     return float(load().mcamd_cnd_f32(x))
 
@@ -203,6 +214,15 @@ class Context:
         res = Result()
         _check(self._L.mcamd_price_paths(self._h, C.byref(opt), C.byref(sim), C.byref(res)))
         return res
+
+    def price_paths_enqueue(self, opt: Option, sim: Sim, stats) -> None:
+        """Asynchronous: leaves {sum, sumsq, sum_c, sum_cc, sum_yc, n} in the device tensor `stats` (>= 6 doubles)."""
+        _check(self._L.mcamd_price_paths_enqueue(self._h, C.byref(opt), C.byref(sim), _ptr(stats)))
+
+    def enqueued_kernel_ms(self, n_last: int):
+        arr = (C.c_float * n_last)()
+        _check(self._L.mcamd_enqueued_kernel_ms(self._h, n_last, arr))
+        return list(arr)
 
     def simulate_trajectories(self, opt: Option, sim: Sim, traj, counts=None, payoffs=None,
                               layout=STEP_MAJOR) -> Result:

@@ -221,9 +221,12 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(const T *__restrict__ in
 // of the single workgroup is overlapped.
 constexpr int kFinalBlock = 1024;
 
+// n_value >= 0 selects the asynchronous "stats" layout: out[0..5) = {sum, sumsq, sum_c, sum_cc, sum_yc}
+// (zeros where N = 2) and out[5] = n_value, so one all-reduce of 6 doubles carries a whole shard.
 template <int N>
 __global__ __launch_bounds__(kFinalBlock) void final_reduce_kernel(const double *__restrict__ partials,
-                                                                  uint32_t n_records, double *__restrict__ out)
+                                                                  uint32_t n_records, double *__restrict__ out,
+                                                                  double n_value)
 {
     double s[4][N];
 #pragma unroll
@@ -247,16 +250,23 @@ __global__ __launch_bounds__(kFinalBlock) void final_reduce_kernel(const double 
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < N; ++k) out[k] = v[k];
+        if (n_value >= 0.0) {
+#pragma unroll
+            for (int k = N; k < 5; ++k) out[k] = 0.0;
+            out[5] = n_value;
+        }
     }
 }
 
 hipError_t launch_final_reduce(const double *d_partials, uint32_t n_records, int record_doubles, double *d_out,
-                               hipStream_t stream)
+                               hipStream_t stream, double n_value)
 {
     if (record_doubles == 5)
-        hipLaunchKernelGGL(final_reduce_kernel<5>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out);
+        hipLaunchKernelGGL(final_reduce_kernel<5>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out,
+                           n_value);
     else
-        hipLaunchKernelGGL(final_reduce_kernel<2>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out);
+        hipLaunchKernelGGL(final_reduce_kernel<2>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out,
+                           n_value);
     return hipGetLastError();
 }
 

@@ -52,6 +52,10 @@ struct mcamd_ctx {
     uint64_t partial_capacity = 0; // in doubles
     double *d_out = nullptr;       // 8 doubles
     double *h_out = nullptr;       // pinned, 8 doubles
+    // asynchronous calls: a ring of event pairs around the simulation kernel of the last kRing enqueues
+    static constexpr uint32_t kRing = 64;
+    hipEvent_t ring0[kRing] = {}, ring1[kRing] = {};
+    uint64_t n_enqueued = 0;
 };
 
 namespace {
@@ -242,6 +246,10 @@ int mcamd_ctx_create(int device, void *hip_stream, mcamd_ctx **out)
     hipError_t e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
+    for (uint32_t i = 0; i < mcamd_ctx::kRing && e == hipSuccess; ++i) {
+        e = hipEventCreate(&ctx->ring0[i]);
+        if (e == hipSuccess) e = hipEventCreate(&ctx->ring1[i]);
+    }
     if (e == hipSuccess) e = hipMalloc(&ctx->d_out, 8 * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc(&ctx->h_out, 8 * sizeof(double), hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -263,6 +271,10 @@ int mcamd_ctx_destroy(mcamd_ctx *ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+    for (uint32_t i = 0; i < mcamd_ctx::kRing; ++i) {
+        if (ctx->ring0[i]) (void)hipEventDestroy(ctx->ring0[i]);
+        if (ctx->ring1[i]) (void)hipEventDestroy(ctx->ring1[i]);
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MCAMD_OK;
@@ -363,6 +375,59 @@ int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *
     res->total_ms = tms;
     res->grid = grid;
     res->block = 256;
+    return MCAMD_OK;
+}
+
+int mcamd_price_paths_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, double *d_stats)
+{
+    mcamd_result dummy;
+    if (int rc = check_common(ctx, opt, sim, &dummy)) return rc;
+    if (!d_stats) return fail(MCAMD_ERR_INVALID, "d_stats is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t slot = static_cast<uint32_t>(ctx->n_enqueued % mcamd_ctx::kRing);
+    if (sim->n_paths_local == 0) {  // empty shard: all-zero statistics, still ordered on the stream
+        HIP_TRY(hipMemsetAsync(d_stats, 0, 6 * sizeof(double), ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ring0[slot], ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ring1[slot], ctx->stream));
+        ctx->n_enqueued++;
+        return MCAMD_OK;
+    }
+    const mcamd::PathJob job = make_job(opt, sim);
+    const int rec = (job.vr & 2) ? 5 : 2;
+    const uint32_t grid = mcamd::price_grid(job.n_local, job.n_sim);
+    // growing the scratch buffer frees the old one: wait for work that may still read it
+    if (static_cast<uint64_t>(grid) * rec > ctx->partial_capacity) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (int rc = ensure_partials(ctx, grid, rec)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ring0[slot], ctx->stream));
+    HIP_TRY(mcamd::launch_price(job, ctx->d_partials, grid, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ring1[slot], ctx->stream));
+    HIP_TRY(mcamd::launch_final_reduce(ctx->d_partials, grid, rec, d_stats, ctx->stream,
+                                       static_cast<double>(sim->n_paths_local)));
+    ctx->n_enqueued++;
+    return MCAMD_OK;
+}
+
+int mcamd_enqueued_kernel_ms(mcamd_ctx *ctx, uint32_t n_last, float *ms)
+{
+    if (!ctx || !ms) return fail(MCAMD_ERR_INVALID, "ctx and ms must be non-NULL");
+    if (n_last > mcamd_ctx::kRing || n_last > ctx->n_enqueued)
+        return fail(MCAMD_ERR_INVALID, "only the last min(%u, enqueued) calls are kept", mcamd_ctx::kRing);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < n_last; ++i) {
+        const uint32_t slot = static_cast<uint32_t>((ctx->n_enqueued - n_last + i) % mcamd_ctx::kRing);
+        HIP_TRY(hipEventElapsedTime(&ms[i], ctx->ring0[slot], ctx->ring1[slot]));
+    }
+    return MCAMD_OK;
+}
+
+int mcamd_finalize_stats(const double stats[6], double r, double T, int control_variate, mcamd_result *res)
+{
+    if (!stats || !res) return fail(MCAMD_ERR_INVALID, "stats and res must be non-NULL");
+    zero_result(res);
+    const uint64_t n = static_cast<uint64_t>(std::llround(stats[5]));
+    if (control_variate) finalize_cv_into(stats, n, r, T, res);
+    else finalize_into(stats[0], stats[1], n, r, T, res);
     return MCAMD_OK;
 }
 

@@ -39,8 +39,9 @@ hipError_t launch_from_normals(const PathJob &job, const void *d_normals, void *
                                uint32_t grid, hipStream_t stream);
 
 // sums n_records records of record_doubles (2 or 5) doubles into d_out[0..record_doubles)
+// n_value >= 0: also zero-fill d_out[record_doubles..5) and write d_out[5] = n_value (the 6-double stats layout)
 hipError_t launch_final_reduce(const double *d_partials, uint32_t n_records, int record_doubles, double *d_out,
-                               hipStream_t stream);
+                               hipStream_t stream, double n_value = -1.0);
 
 hipError_t launch_generate_normals(uint64_t seed, uint64_t n, int precision, void *d_out, hipStream_t stream);
 

@@ -207,6 +207,31 @@ def test_price_paths_grid_stride_beyond_max_grid(ctx):
     assert abs(whole.price - BS) <= 4 * whole.std_err
 
 
+def test_price_paths_enqueue_matches_synchronous_call(ctx):
+    # asynchronous form: kernel + final reduce enqueued, statistics left in a device buffer; many calls in flight
+    opt = capi.make_option(**BENCH)
+    stats = torch.full((6, 8), -1.0, dtype=torch.float64, device="cuda")
+    sims = [capi.make_sim(100_000 + 7 * i, 5 + i, capi.F64 if i % 2 else capi.F32, seed=40 + i,
+                          flags=(capi.FLAG_CONTROL_VARIATE | capi.FLAG_ANTITHETIC) if i == 3 else 0) for i in range(5)]
+    sims.append(capi.make_sim(10, 3, capi.F64, n_paths_local=0))            # empty shard
+    for i, sim in enumerate(sims):
+        ctx.price_paths_enqueue(opt, sim, stats[i])
+    torch.cuda.synchronize()
+    for i, sim in enumerate(sims):
+        want = ctx.price_paths(opt, sim)
+        got = stats[i].tolist()
+        assert got[0] == want.sum and got[1] == want.sumsq and got[5] == want.n, i
+        assert got[2] == want.sum_c and got[3] == want.sum_cc and got[4] == want.sum_yc
+        fin = capi.finalize_stats(got[:6], opt.r, opt.T, control_variate=(i == 3))
+        assert fin.price == want.price and fin.std_err == want.std_err
+    ms = ctx.enqueued_kernel_ms(6)
+    assert len(ms) == 6 and all(m >= 0 for m in ms) and ms[4] > 0
+    with pytest.raises(capi.McamdError):
+        ctx.enqueued_kernel_ms(65)
+    with pytest.raises(capi.McamdError):
+        ctx.price_paths_enqueue(opt, sims[0], None)
+
+
 def test_price_paths_empty_shard_and_errors(ctx):
     res = ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(100, 3, capi.F64, n_paths_local=0))
     assert res.sum == 0 and res.n == 0

@@ -170,7 +170,12 @@ def main():
         n_total = per_gpu * world
         lo = rank * per_gpu
     opt = capi.make_option(**OPTION)
-    stream = torch.cuda.current_stream()
+    # One explicit stream for everything: the library launches on it, torch allocates / reduces on it (made the
+    # current stream), so "enqueue kernel -> all-reduce its output" is ordered on the device with no host sync.
+    # (torch's default stream has handle 0, which the C ABI reads as "create your own stream".)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     ctx = capi.Context(device_index, stream.cuda_stream)
 
     traj = None

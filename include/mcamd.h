@@ -148,7 +148,10 @@ const char *mcamd_last_error(void);
 int mcamd_device_count(int *count);
 
 /* hip_stream: a hipStream_t to launch on (e.g. the caller framework's current stream), or NULL
- * to let the context create its own.  Scratch buffers are owned by the context and reused. */
+ * to let the context create its own non-blocking stream.  Note that the legacy default stream's handle IS
+ * NULL (torch.cuda.current_stream().cuda_stream == 0 unless a stream was made current): to share the default
+ * stream pass hipStreamLegacy, or — as bench.py does — make an explicit stream current and pass that.
+ * Scratch buffers are owned by the context and reused. */
 int mcamd_ctx_create(int device, void *hip_stream, mcamd_ctx **ctx);
 int mcamd_ctx_destroy(mcamd_ctx *ctx);
 int mcamd_get_device_info(mcamd_ctx *ctx, mcamd_device_info *info);

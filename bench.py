@@ -200,7 +200,10 @@ def main():
         if is_price:
             ctx.price_paths_enqueue(opt, capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu), stats[slot])
             if world > 1:
-                dist.all_reduce(stats[slot])   # the one collective of the path: (sum, sumsq, .., n) over RCCL/xGMI
+                # the one collective of the path: the 6-double record over RCCL/xGMI.  async_op: the collective
+                # waits for this step's kernels, but the NEXT step's kernels do not wait for the collective —
+                # it runs on RCCL's own stream underneath them; everything is joined once after the K steps.
+                pending.append(dist.all_reduce(stats[slot], async_op=True))
             return None, None
         if wl == "store":
             sim = capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu)
@@ -216,7 +219,12 @@ def main():
             fin = res
         return res, fin
 
+    pending = []
+
     def fence():
+        for w in pending:
+            w.wait()
+        pending.clear()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

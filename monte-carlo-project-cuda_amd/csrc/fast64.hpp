@@ -74,6 +74,38 @@ MC_HD double rsq_seed(double a)
 #endif
 }
 
+// Three-address fused multiply-adds for the places where hipcc (ROCm 7.2) otherwise picks the two-address
+// v_fmac_f64 and has to copy a loop-invariant addend into a fresh accumulator first (a v_mov_b64, or two
+// v_mov_b32 from SGPRs, per use: ~6 % of the fp64 step loop).  One VALU instruction each, register operands
+// only; their inputs never come straight from a transcendental op, so no wait state is owed inside.
+//   fma_us(a, k)      a * k + k         k wave-uniform (SGPR pair used twice)
+//   fma_usv(a, k, c)  a * k + c         k wave-uniform, c a value kept in VGPRs (loop-invariant constant)
+//   fma_vvs(a, b, k)  a * b + k         k wave-uniform
+#if defined(__HIP_DEVICE_COMPILE__)
+MC_HD double fma_us(double a, double k)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %2" : "=v"(d) : "v"(a), "s"(k));
+    return d;
+}
+MC_HD double fma_usv(double a, double k, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+    return d;
+}
+MC_HD double fma_vvs(double a, double b, double k)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+    return d;
+}
+#else
+MC_HD double fma_us(double a, double k) { return __builtin_fma(a, k, k); }
+MC_HD double fma_usv(double a, double k, double c) { return __builtin_fma(a, k, c); }
+MC_HD double fma_vvs(double a, double b, double k) { return __builtin_fma(a, b, k); }
+#endif
+
 // (v + 1) * c with v = x ^ (y << 21) the 53-bit integer rocRAND builds from two Philox words
 // (rocrand_normal.h box_muller_double).  v = hi 2^32 + lo is exact in a double (v < 2^53), and
 // fma(v, c, c) is rocRAND's own expression; with c a power of two the result is exact.
@@ -84,7 +116,7 @@ MC_HD double u53(uint32_t x, uint32_t y, double c)
     const uint32_t lo = x ^ (y << 21);
     const uint32_t hi = y >> 11;
     const double v = __builtin_fma(static_cast<double>(hi), 0x1p32, static_cast<double>(lo));
-    return __builtin_fma(v, c, c);
+    return fma_us(v, c);
 }
 
 #include "tables64_consts.inc"
@@ -102,7 +134,7 @@ MC_HD double neg2log(double u, const D2 *tab)
     const D2 e = tab[i];
     const double t = __builtin_fma(z, e.a, 2.0);
     const double w = __builtin_fma(static_cast<double>(k), kM2Ln2, e.b);
-    double q = __builtin_fma(t, 1.0 / 192.0, 1.0 / 80.0);
+    double q = fma_usv(t, 1.0 / 192.0, 1.0 / 80.0);
     q = __builtin_fma(t, q, 1.0 / 32.0);
     q = __builtin_fma(t, q, 1.0 / 12.0);
     q = __builtin_fma(t, q, 0.25);
@@ -134,7 +166,7 @@ MC_HD void sincos_q(double q, const D2 *tab, double &s, double &c)
     const D2 e = tab[ji & 511];
     const double d = f * kTwoPiOverN;
     const double z = d * d;
-    const double sp = __builtin_fma(z, 1.0 / 120.0, -1.0 / 6.0);
+    const double sp = fma_usv(z, 1.0 / 120.0, -1.0 / 6.0);
     const double sd = __builtin_fma(d * z, sp, d);
     const double cp = __builtin_fma(z, 1.0 / 24.0, -0.5);
     const double cd = __builtin_fma(z, cp, 1.0);
@@ -155,7 +187,7 @@ MC_HD double mul_exp(double S, double x, const double *tab)
     const double tv = tab[ki & 511];
     const uint32_t bump = (static_cast<uint32_t>(ki) & 0xfffffe00u) << 11;  // (k >> 9) << 20
     const double sc = make_double(lo32(tv), hi32(tv) + bump);
-    double p = __builtin_fma(r, 1.0 / 24.0, 1.0 / 6.0);
+    double p = fma_usv(r, 1.0 / 24.0, 1.0 / 6.0);
     p = __builtin_fma(r, p, 0.5);
     const double tmp = __builtin_fma(r * r, p, r);
     const double Ss = S * sc;

@@ -224,8 +224,8 @@ struct Exponents<double> {
         const double sv = f64::sqrt_pos(f64::neg2log(u, m.t.log_tab)) * c.vol_bm;
         double sn, cs;
         f64::sincos_q(q, m.t.sincos_tab, sn, cs);
-        x[0] = __builtin_fma(sn, sv, c.drift);
-        x[1] = __builtin_fma(cs, sv, c.drift);
+        x[0] = f64::fma_vvs(sn, sv, c.drift);
+        x[1] = f64::fma_vvs(cs, sv, c.drift);
     }
 };
 

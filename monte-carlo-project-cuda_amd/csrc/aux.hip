@@ -190,7 +190,11 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(const T *__restrict__ in
         for (uint64_t i = n_vec * V + gtid; i < n; i += stride) v += static_cast<double>(in[i]);
         block_sum2<kBlock>(v, zero);
     } else {
-        v = load2(in, n, static_cast<uint64_t>(blockIdx.x) * (2 * kBlock) + tid);
+        // first add on load: two elements per thread per chunk; the grid is capped at kMaxGrid blocks, so
+        // for very large n a block walks several chunks before its tree
+        const uint64_t chunk_stride = static_cast<uint64_t>(gridDim.x) * (2 * kBlock);
+        for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * (2 * kBlock); base < n; base += chunk_stride)
+            v += load2(in, n, base + tid);
         if (VARIANT == MCAMD_REDUCE_SEQUENTIAL) {
             sdata[tid] = v;
             __syncthreads();

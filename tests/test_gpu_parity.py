@@ -430,6 +430,18 @@ def test_reduce_sum_vs_host_fp64(ctx, variant, prec, n):
     assert math.isclose(s, want, rel_tol=1e-12, abs_tol=1e-9 * max(1.0, math.sqrt(n)))
 
 
+@pytest.mark.parametrize("variant", [3, 4, 5, 6])
+def test_reduce_sum_beyond_max_grid(ctx, variant):
+    # 2^30 + 3 elements: variants 3-5 would need 2^21 blocks; the grid is capped at 2^20, blocks must stride
+    n = (1 << 30) + 3
+    x = torch.ones(n, dtype=torch.float32, device="cuda")
+    x[-1] = 5.0
+    s, _ = ctx.reduce_sum(x, n, capi.F32, variant)
+    assert s == float(n) + 4.0
+    del x
+    torch.cuda.empty_cache()
+
+
 def test_reduce_misaligned_input(ctx):
     x = torch.randn(10_001, dtype=torch.float32, device="cuda")
     s, _ = ctx.reduce_sum(x.data_ptr() + 4, 10_000, capi.F32, 6)

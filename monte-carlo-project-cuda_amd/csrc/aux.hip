@@ -22,7 +22,9 @@ struct ArrayArgs {
     T *payoffs;
 };
 
-template <typename T, bool WINDOW>
+// VEC: every path row starts 16-byte aligned (n_sim a multiple of 16 / sizeof(T), aligned buffer): a lane
+// fetches 16 bytes, so one wave-wide load covers 8 path rows x 128 bytes instead of 2.
+template <typename T, bool WINDOW, bool VEC>
 __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, double *__restrict__ partials)
 {
     constexpr int kWaves = kBlock / kWave;
@@ -46,10 +48,26 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
         for (uint32_t s0 = 0; s0 < c.n_sim; s0 += TS) {
             const uint32_t n_cols = (c.n_sim - s0 < static_cast<uint32_t>(TS)) ? c.n_sim - s0 : TS;
             // stage: global reads are contiguous along a path's row, LDS holds [path][step]
-            for (int r = 0; r < kWave; r += kRowsPerLoad) {
-                const uint64_t p = path0 + r + lrow;
-                if (p < a.n_local && static_cast<uint32_t>(lcol) < n_cols)
-                    tile[wave][r + lrow][lcol] = a.normals[p * c.n_sim + s0 + lcol];
+            if (VEC) {
+                constexpr int V = 16 / sizeof(T);        // elements per lane per load
+                constexpr int kLanesPerRow = TS / V;     // 8
+                constexpr int kRowsPerVecLoad = kWave / kLanesPerRow;
+                using VT = T __attribute__((ext_vector_type(V)));
+                const int vrow = lane / kLanesPerRow, vcol = (lane % kLanesPerRow) * V;
+                for (int r = 0; r < kWave; r += kRowsPerVecLoad) {
+                    const uint64_t p = path0 + r + vrow;
+                    if (p < a.n_local && static_cast<uint32_t>(vcol) < n_cols) {
+                        const VT v = *reinterpret_cast<const VT *>(a.normals + p * c.n_sim + s0 + vcol);
+#pragma unroll
+                        for (int k = 0; k < V; ++k) tile[wave][r + vrow][vcol + k] = v[k];
+                    }
+                }
+            } else {
+                for (int r = 0; r < kWave; r += kRowsPerLoad) {
+                    const uint64_t p = path0 + r + lrow;
+                    if (p < a.n_local && static_cast<uint32_t>(lcol) < n_cols)
+                        tile[wave][r + lrow][lcol] = a.normals[p * c.n_sim + s0 + lcol];
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -89,10 +107,15 @@ static hipError_t launch_from_normals_t(const PathJob &j, const void *d_normals,
                                         uint32_t grid, hipStream_t stream)
 {
     ArrayArgs<T> a{make_consts<T>(j), j.n_local, static_cast<const T *>(d_normals), static_cast<T *>(d_payoffs)};
-    if (j.window)
-        hipLaunchKernelGGL((from_normals_kernel<T, true>), dim3(grid), dim3(kBlock), 0, stream, a, d_partials);
-    else
-        hipLaunchKernelGGL((from_normals_kernel<T, false>), dim3(grid), dim3(kBlock), 0, stream, a, d_partials);
+    const bool vec = (j.n_sim % (16 / sizeof(T)) == 0) && (reinterpret_cast<uintptr_t>(d_normals) % 16 == 0);
+    const dim3 g(grid), b(kBlock);
+    if (j.window) {
+        if (vec) hipLaunchKernelGGL((from_normals_kernel<T, true, true>), g, b, 0, stream, a, d_partials);
+        else hipLaunchKernelGGL((from_normals_kernel<T, true, false>), g, b, 0, stream, a, d_partials);
+    } else {
+        if (vec) hipLaunchKernelGGL((from_normals_kernel<T, false, true>), g, b, 0, stream, a, d_partials);
+        else hipLaunchKernelGGL((from_normals_kernel<T, false, false>), g, b, 0, stream, a, d_partials);
+    }
     return hipGetLastError();
 }
 

@@ -143,6 +143,29 @@ int finish(mcamd_ctx *ctx, uint32_t records, mcamd_result *res, int record_doubl
     return MCAMD_OK;
 }
 
+void finalize_cv_into(const double s[5], uint64_t n, double r, double T, mcamd_result *res);
+void finalize_into(double sum, double sumsq, uint64_t n, double r, double T, mcamd_result *res);
+
+// Common tail of the pricing calls: final reduce + copy + sync, then price / SE / CI from the shard's sums,
+// keeping the event timings and the launch shape in the result.
+int finish_pricing(mcamd_ctx *ctx, uint32_t grid, int record_doubles, const mcamd_option *opt, const mcamd_sim *sim,
+                   mcamd_result *res)
+{
+    if (int rc = finish(ctx, grid, res, record_doubles)) return rc;
+    const float kms = res->kernel_ms, tms = res->total_ms;
+    if (record_doubles == 5) {
+        const double sums[5] = {res->sum, res->sumsq, res->sum_c, res->sum_cc, res->sum_yc};
+        finalize_cv_into(sums, sim->n_paths_local, opt->r, opt->T, res);
+    } else {
+        finalize_into(res->sum, res->sumsq, sim->n_paths_local, opt->r, opt->T, res);
+    }
+    res->kernel_ms = kms;
+    res->total_ms = tms;
+    res->grid = grid;
+    res->block = 256;
+    return MCAMD_OK;
+}
+
 void finalize_cv_into(const double s[5], uint64_t n, double r, double T, mcamd_result *res)
 {
     const double disc = std::exp(-r * T);
@@ -363,19 +386,7 @@ int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *
     if (int rc = ensure_partials(ctx, grid, rec)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(mcamd::launch_price(job, ctx->d_partials, grid, ctx->stream));
-    if (int rc = finish(ctx, grid, res, rec)) return rc;
-    const float kms = res->kernel_ms, tms = res->total_ms;
-    if (rec == 5) {
-        const double sums[5] = {res->sum, res->sumsq, res->sum_c, res->sum_cc, res->sum_yc};
-        finalize_cv_into(sums, sim->n_paths_local, opt->r, opt->T, res);
-    } else {
-        finalize_into(res->sum, res->sumsq, sim->n_paths_local, opt->r, opt->T, res);
-    }
-    res->kernel_ms = kms;
-    res->total_ms = tms;
-    res->grid = grid;
-    res->block = 256;
-    return MCAMD_OK;
+    return finish_pricing(ctx, grid, rec, opt, sim, res);
 }
 
 int mcamd_price_paths_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, double *d_stats)
@@ -454,14 +465,7 @@ int mcamd_simulate_trajectories(mcamd_ctx *ctx, const mcamd_option *opt, const m
     if (int rc = ensure_partials(ctx, grid)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(mcamd::launch_store(job, layout, d_traj, d_counts, d_payoffs, ctx->d_partials, grid, ctx->stream));
-    if (int rc = finish(ctx, grid, res)) return rc;
-    const float kms = res->kernel_ms, tms = res->total_ms;
-    finalize_into(res->sum, res->sumsq, sim->n_paths_local, opt->r, opt->T, res);
-    res->kernel_ms = kms;
-    res->total_ms = tms;
-    res->grid = grid;
-    res->block = 256;
-    return MCAMD_OK;
+    return finish_pricing(ctx, grid, 2, opt, sim, res);
 }
 
 int mcamd_price_from_normals(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, const void *d_normals,
@@ -479,14 +483,7 @@ int mcamd_price_from_normals(mcamd_ctx *ctx, const mcamd_option *opt, const mcam
     if (int rc = ensure_partials(ctx, grid)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(mcamd::launch_from_normals(job, d_normals, d_payoffs, ctx->d_partials, grid, ctx->stream));
-    if (int rc = finish(ctx, grid, res)) return rc;
-    const float kms = res->kernel_ms, tms = res->total_ms;
-    finalize_into(res->sum, res->sumsq, sim->n_paths_local, opt->r, opt->T, res);
-    res->kernel_ms = kms;
-    res->total_ms = tms;
-    res->grid = grid;
-    res->block = 256;
-    return MCAMD_OK;
+    return finish_pricing(ctx, grid, 2, opt, sim, res);
 }
 
 int mcamd_generate_normals(mcamd_ctx *ctx, uint64_t seed, uint64_t n, int precision, void *d_out, float *kernel_ms)

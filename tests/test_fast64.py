@@ -28,3 +28,13 @@ def test_tables_are_reproducible_from_the_generator():
     before = open(inc).read()
     subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_tables64.py")], stdout=subprocess.DEVNULL)
     assert open(inc).read() == before
+
+
+def test_fast64_clean_under_asan_ubsan(tmp_path):
+    # host-side sanitizer run of the same header (GPU sanitizers are not available on the pool)
+    exe = tmp_path / "f64check_san"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-I" + os.path.join(ROOT, "monte-carlo-project-cuda_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host_fast64_check.cpp"), "-o", str(exe)])
+    r = json.loads(subprocess.check_output([str(exe), "200000"]))
+    assert r["uniform_mismatch"] == 0 and r["neg2log_ulp"] <= 2.0

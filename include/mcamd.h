@@ -234,6 +234,20 @@ int mcamd_nmc_inner(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
 int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, uint64_t outer_seed, int layout,
                     void *d_prices, int32_t *d_counts, void *d_point_prices, mcamd_result *res);
 
+/* ---- single-process multi-GPU (the shape of the reference's own main(): one host process) ----
+ * A group owns one context per device and an RCCL communicator clique over them (ncclCommInitAll; RCCL is loaded
+ * with dlopen on first use).  mcamd_group_price_paths splits [path_offset, path_offset + n_paths_local) of the job
+ * into contiguous per-device shards, runs them concurrently (mcamd_price_paths_enqueue on every device), sums the
+ * 6-double statistics records with ONE ncclAllReduce over xGMI and finalizes.  Because a path's random numbers
+ * depend only on its global id, the result equals the single-device result up to fp64 summation order.
+ * devices == NULL: devices 0..n_devices-1; n_devices <= 0: all visible devices.  The reference has no multi-GPU
+ * code.  One-process-per-GPU hosts use mcamd_price_paths_enqueue + their own collective (bench.py). */
+typedef struct mcamd_group mcamd_group;
+int mcamd_group_create(int n_devices, const int *devices, mcamd_group **group);
+int mcamd_group_destroy(mcamd_group *group);
+int mcamd_group_size(mcamd_group *group, int *n_devices);
+int mcamd_group_price_paths(mcamd_group *group, const mcamd_option *opt, const mcamd_sim *sim, mcamd_result *res);
+
 /* Host: discount + mean + standard error + 95% CI from (sum, sumsq, n) — after an all-reduce
  * over shards, or directly.  Fills price/std_err/ci_* (and copies sum/sumsq/n) in *res. */
 int mcamd_finalize(double sum, double sumsq, uint64_t n, double r, double T, mcamd_result *res);

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libmcamd.so")
-SOURCES = ["price_f64.hip", "price_f32.hip", "store.hip", "aux.hip", "nmc.hip", "capi.cpp"]
+SOURCES = ["price_f64.hip", "price_f32.hip", "store.hip", "aux.hip", "nmc.hip", "capi.cpp", "group.cpp"]
 HEADERS = ["launch.hpp", "mc_device.hpp", "path_consts.hpp", "fast64.hpp", "tables64.inc", "tables64_consts.inc",
            "price_impl.hpp"]
 ARCH = "gfx950"
@@ -57,7 +57,7 @@ def build(force: bool = False, extra_flags=(), jobs: int = 6) -> str:
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, tuple(extra_flags)), SOURCES))
     if force or _stale(LIB, objs):
-        subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", LIB])
+        subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", LIB, "-ldl"])
     return LIB
 
 

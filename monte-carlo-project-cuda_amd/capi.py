@@ -24,7 +24,8 @@ EXPORTS = [
     "mcamd_abi_version", "mcamd_last_error", "mcamd_device_count", "mcamd_ctx_create", "mcamd_ctx_destroy",
     "mcamd_get_device_info", "mcamd_device_malloc", "mcamd_device_free", "mcamd_memcpy_to_host",
     "mcamd_memcpy_to_device", "mcamd_price_paths", "mcamd_price_paths_enqueue", "mcamd_enqueued_kernel_ms",
-    "mcamd_finalize_stats", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
+    "mcamd_finalize_stats", "mcamd_group_create", "mcamd_group_destroy", "mcamd_group_size",
+    "mcamd_group_price_paths", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
     "mcamd_generate_normals", "mcamd_reduce_sum", "mcamd_nmc_inner", "mcamd_nmc_fused", "mcamd_finalize", "mcamd_finalize_cv", "mcamd_cnd_f32",
     "mcamd_bs_call_f32", "mcamd_bs_call_f64",
 ]
@@ -94,6 +95,10 @@ def load() -> C.CDLL:
     L.mcamd_price_paths_enqueue.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), vp]
     L.mcamd_enqueued_kernel_ms.argtypes = [vp, C.c_uint32, C.POINTER(f32)]
     L.mcamd_finalize_stats.argtypes = [C.POINTER(f64), f64, f64, i32, C.POINTER(Result)]
+    L.mcamd_group_create.argtypes = [i32, C.POINTER(i32), C.POINTER(vp)]
+    L.mcamd_group_destroy.argtypes = [vp]
+    L.mcamd_group_size.argtypes = [vp, C.POINTER(i32)]
+    L.mcamd_group_price_paths.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), C.POINTER(Result)]
     L.mcamd_simulate_trajectories.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, vp, vp, vp,
                                               C.POINTER(Result)]
     L.mcamd_price_from_normals.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), vp, vp, C.POINTER(Result)]
@@ -259,4 +264,35 @@ class Context:
         res = Result()
         _check(self._L.mcamd_nmc_fused(self._h, C.byref(opt), C.byref(sim), outer_seed, layout, _ptr(prices),
                                        _ptr(counts), _ptr(point_prices), C.byref(res)))
+        return res
+
+
+class Group:
+    """Single-process multi-GPU group: one context per device + an RCCL communicator clique (mcamd_group_*)."""
+
+    def __init__(self, n_devices: int = 0, devices=None):
+        self._L = load()
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices) if devices else None
+        _check(self._L.mcamd_group_create(len(devices) if devices else n_devices, arr, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._L.mcamd_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def size(self) -> int:
+        n = C.c_int(0)
+        _check(self._L.mcamd_group_size(self._h, C.byref(n)))
+        return n.value
+
+    def price_paths(self, opt: Option, sim: Sim) -> Result:
+        res = Result()
+        _check(self._L.mcamd_group_price_paths(self._h, C.byref(opt), C.byref(sim), C.byref(res)))
         return res

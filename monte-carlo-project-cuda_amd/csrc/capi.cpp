@@ -43,6 +43,13 @@ int fail(int code, const char *fmt, ...)
 
 }  // namespace
 
+// used by group.cpp: records the calling thread's last error message
+int mcamd_set_error_(int code, const char *msg)
+{
+    g_last_error = msg ? msg : "";
+    return code;
+}
+
 struct mcamd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -1,0 +1,193 @@
+// group.cpp — single-process multi-GPU entry points of the C ABI (mcamd_group_*): one context per device,
+// path-sharded pricing on all devices at once, and ONE RCCL all-reduce of the 6-double statistics record
+// over xGMI.  This is the route for a C++ host (the reference's main() is a single process); bench.py uses
+// the other standard shape, one process per GPU with torch.distributed, on the same enqueue primitive.
+//
+// The reference has no multi-GPU code.  Shards are contiguous global path-id ranges, and the
+// Philox subsequence of a path is its global id, so the result equals the single-GPU result up to fp64
+// summation order.  RCCL is loaded with dlopen when the first group is created: libmcamd.so keeps no link-time
+// dependency on it, and a process that already carries an RCCL (PyTorch ships its own) reuses that one.
+#include "mcamd.h"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+int mcamd_set_error_(int code, const char *msg);  // capi.cpp: records the thread's last error string
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.handle) return MCAMD_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return mcamd_set_error_(MCAMD_ERR_HIP, "RCCL not found (dlopen librccl.so.1): multi-GPU groups need it");
+    Rccl r;
+    r.handle = h;
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.AllReduce || !r.GetErrorString)
+        return mcamd_set_error_(MCAMD_ERR_HIP, "RCCL library lacks an expected symbol");
+    g_rccl = r;
+    return MCAMD_OK;
+}
+
+int nccl_fail(ncclResult_t e, const char *what)
+{
+    std::string msg = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "RCCL error");
+    return mcamd_set_error_(MCAMD_ERR_HIP, msg.c_str());
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    (void)hipGetLastError();
+    std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+    return mcamd_set_error_(e == hipErrorOutOfMemory ? MCAMD_ERR_NOMEM : MCAMD_ERR_HIP, msg.c_str());
+}
+
+}  // namespace
+
+struct mcamd_group {
+    std::vector<int> devices;
+    std::vector<mcamd_ctx *> ctx;
+    std::vector<hipStream_t> streams;
+    std::vector<double *> d_stats;  // 8 doubles per device
+    std::vector<ncclComm_t> comms;
+};
+
+extern "C" {
+
+int mcamd_group_create(int n_devices, const int *devices, mcamd_group **out)
+{
+    if (!out) return mcamd_set_error_(MCAMD_ERR_INVALID, "group out-pointer is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        return mcamd_set_error_(MCAMD_ERR_NODEVICE, "no HIP device visible: this engine has no CPU fallback");
+    }
+    if (n_devices <= 0) n_devices = count;  // all visible devices
+    if (n_devices > count) return mcamd_set_error_(MCAMD_ERR_INVALID, "more devices requested than visible");
+    if (int rc = load_rccl()) return rc;
+    mcamd_group *g = new (std::nothrow) mcamd_group;
+    if (!g) return mcamd_set_error_(MCAMD_ERR_NOMEM, "out of host memory");
+    for (int i = 0; i < n_devices; ++i) g->devices.push_back(devices ? devices[i] : i);
+    for (int i = 0; i < n_devices; ++i) {
+        mcamd_ctx *c = nullptr;
+        hipStream_t s = nullptr;
+        double *d = nullptr;
+        int rc = MCAMD_OK;
+        hipError_t e = hipSetDevice(g->devices[i]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(&d, 8 * sizeof(double));
+        if (e != hipSuccess) rc = hip_fail(e, "group device setup");
+        if (!rc) rc = mcamd_ctx_create(g->devices[i], s, &c);
+        g->ctx.push_back(c);
+        g->streams.push_back(s);
+        g->d_stats.push_back(d);
+        if (rc) {
+            mcamd_group_destroy(g);
+            return rc;
+        }
+    }
+    g->comms.resize(n_devices, nullptr);
+    // single-process communicator clique over the device list: the RCCL ring/tree runs over xGMI
+    ncclResult_t ne = g_rccl.CommInitAll(g->comms.data(), n_devices, g->devices.data());
+    if (ne != ncclSuccess) {
+        g->comms.clear();
+        mcamd_group_destroy(g);
+        return nccl_fail(ne, "ncclCommInitAll");
+    }
+    *out = g;
+    return MCAMD_OK;
+}
+
+int mcamd_group_destroy(mcamd_group *g)
+{
+    if (!g) return MCAMD_OK;
+    for (size_t i = 0; i < g->comms.size(); ++i)
+        if (g->comms[i]) (void)g_rccl.CommDestroy(g->comms[i]);
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        (void)hipSetDevice(g->devices[i]);
+        if (g->ctx[i]) (void)mcamd_ctx_destroy(g->ctx[i]);
+        if (g->d_stats[i]) (void)hipFree(g->d_stats[i]);
+        if (g->streams[i]) (void)hipStreamDestroy(g->streams[i]);
+    }
+    delete g;
+    return MCAMD_OK;
+}
+
+int mcamd_group_size(mcamd_group *g, int *n_devices)
+{
+    if (!g || !n_devices) return mcamd_set_error_(MCAMD_ERR_INVALID, "group and n_devices must be non-NULL");
+    *n_devices = static_cast<int>(g->devices.size());
+    return MCAMD_OK;
+}
+
+int mcamd_group_price_paths(mcamd_group *g, const mcamd_option *opt, const mcamd_sim *sim, mcamd_result *res)
+{
+    if (!g || !opt || !sim || !res) return mcamd_set_error_(MCAMD_ERR_INVALID, "group, opt, sim and res must be non-NULL");
+    const int R = static_cast<int>(g->devices.size());
+    // contiguous shards of [path_offset, path_offset + n_paths_local): sizes differ by at most one
+    const uint64_t base = sim->n_paths_local / R, rem = sim->n_paths_local % R;
+    for (int i = 0; i < R; ++i) {
+        mcamd_sim s = *sim;
+        s.path_offset = sim->path_offset + static_cast<uint64_t>(i) * base + (static_cast<uint64_t>(i) < rem ? i : rem);
+        s.n_paths_local = base + (static_cast<uint64_t>(i) < rem ? 1 : 0);
+        // asynchronous: every device starts its shard before any host wait
+        if (int rc = mcamd_price_paths_enqueue(g->ctx[i], opt, &s, g->d_stats[i])) return rc;
+    }
+    // the one collective of the path: (sum, sumsq, sum_c, sum_cc, sum_yc, n) summed over the devices
+    ncclResult_t ne = g_rccl.GroupStart();
+    for (int i = 0; i < R && ne == ncclSuccess; ++i)
+        ne = g_rccl.AllReduce(g->d_stats[i], g->d_stats[i], 6, ncclDouble, ncclSum, g->comms[i], g->streams[i]);
+    if (ne == ncclSuccess) ne = g_rccl.GroupEnd();
+    if (ne != ncclSuccess) return nccl_fail(ne, "ncclAllReduce");
+    double stats[8] = {0};
+    float kernel_ms = 0.0f;
+    for (int i = 0; i < R; ++i) {
+        hipError_t e = hipSetDevice(g->devices[i]);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->streams[i]);
+        if (e != hipSuccess) return hip_fail(e, "group synchronise");
+        float ms = 0.0f;
+        if (int rc = mcamd_enqueued_kernel_ms(g->ctx[i], 1, &ms)) return rc;
+        kernel_ms = std::fmax(kernel_ms, ms);
+    }
+    hipError_t e = hipSetDevice(g->devices[0]);
+    if (e == hipSuccess) e = hipMemcpy(stats, g->d_stats[0], 6 * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "group result copy");
+    if (int rc = mcamd_finalize_stats(stats, opt->r, opt->T, (sim->flags & MCAMD_FLAG_CONTROL_VARIATE) != 0, res)) return rc;
+    res->kernel_ms = kernel_ms;  // slowest device's simulation kernel
+    res->total_ms = kernel_ms;
+    res->block = 256;
+    return MCAMD_OK;
+}
+
+}  // extern "C"

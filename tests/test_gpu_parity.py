@@ -232,6 +232,25 @@ def test_price_paths_enqueue_matches_synchronous_call(ctx):
         ctx.price_paths_enqueue(opt, sims[0], None)
 
 
+def test_group_single_process_rccl_route(ctx):
+    # mcamd_group_*: contexts + ncclCommInitAll + one ncclAllReduce of the statistics record.  One device on this
+    # box, so the clique has one rank; the shard logic and the RCCL calls are the ones an 8-GPU host runs.
+    opt = capi.make_option(**BENCH)
+    with capi.Group(0) as g:
+        assert g.size() >= 1
+        for sim in (capi.make_sim(1_000_003, 12, capi.F64, seed=21),
+                    capi.make_sim(500_000, 7, capi.F32, seed=22, path_offset=12345, n_paths_local=77_777),
+                    capi.make_sim(200_000, 9, capi.F64, seed=23, flags=capi.FLAG_ANTITHETIC | capi.FLAG_CONTROL_VARIATE)):
+            got = g.price_paths(opt, sim)
+            want = ctx.price_paths(opt, sim)
+            assert got.n == want.n
+            assert math.isclose(got.sum, want.sum, rel_tol=1e-12) and math.isclose(got.sumsq, want.sumsq, rel_tol=1e-12)
+            assert math.isclose(got.price, want.price, rel_tol=1e-12) and math.isclose(got.std_err, want.std_err, rel_tol=1e-9)
+            assert got.kernel_ms > 0
+        empty = g.price_paths(opt, capi.make_sim(10, 3, capi.F64, n_paths_local=0))
+        assert empty.n == 0 and empty.sum == 0
+
+
 def test_price_paths_empty_shard_and_errors(ctx):
     res = ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(100, 3, capi.F64, n_paths_local=0))
     assert res.sum == 0 and res.n == 0

@@ -67,3 +67,12 @@ def test_testing_driver_passes_and_writes_csv(built, tmp_path):
     assert rows[0] == "time,trajectory,value"
     assert len(rows) == 1 + 20 * 151            # t=0 row + 150 steps for each of 20 trajectories
     assert rows[1].split(",")[0] == "0" and float(rows[1].split(",")[2]) == 100.0
+
+
+@pytest.mark.gpu
+def test_multi_gpu_cpp_host_runs_on_the_visible_devices(built):
+    out = subprocess.run([os.path.join(built, "multi_gpu"), "4000000", "16", "0"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"devices (\d+) .* price ([0-9.]+) \+- ([0-9.]+) .*closed form ([0-9.]+)", out.stdout)
+    assert m, out.stdout
+    assert int(m.group(1)) >= 1 and abs(float(m.group(2)) - float(m.group(4))) < 4.5 * float(m.group(3))

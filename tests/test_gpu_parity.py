@@ -574,6 +574,25 @@ def test_full_size_config4_properties(ctx):
     assert res.kernel_ms > 100  # sanity: this is seconds of VALU work, not a skipped launch
 
 
+def test_full_size_config5_rank_shard_properties(ctx):
+    # config 5: 1B paths x 252 steps, fp64, path-sharded over 8 GPUs.  One GPU here: simulate what rank 3 of 8 does
+    # (global ids [375M, 500M)) and check that (1) the shard splits exactly into two sub-shards (any sharding of the
+    # job reproduces the same sums), (2) its price is within 4 SE of the closed form, (3) the all-reduce arithmetic —
+    # summing 8 such records — reproduces mcamd_finalize on the totals (host-side, with this shard standing in for all).
+    n_total, world, rank = 1_000_000_000, 8, 3
+    lo, n_local = pkg.sharding.shard_range(n_total, world, rank)
+    assert (lo, n_local) == (375_000_000, 125_000_000)
+    opt = capi.make_option(**BENCH)
+    shard = ctx.price_paths(opt, capi.make_sim(n_total, 252, capi.F64, seed=1234, path_offset=lo, n_paths_local=n_local))
+    cut = 50_000_001
+    a = ctx.price_paths(opt, capi.make_sim(n_total, 252, capi.F64, seed=1234, path_offset=lo, n_paths_local=cut))
+    b = ctx.price_paths(opt, capi.make_sim(n_total, 252, capi.F64, seed=1234, path_offset=lo + cut, n_paths_local=n_local - cut))
+    assert math.isclose(a.sum + b.sum, shard.sum, rel_tol=1e-12) and math.isclose(a.sumsq + b.sumsq, shard.sumsq, rel_tol=1e-12)
+    assert abs(shard.price - BS) <= 4 * shard.std_err and math.isclose(shard.std_err, 16.109 / math.sqrt(n_local), rel_tol=0.01)
+    fin = capi.finalize(8 * shard.sum, 8 * shard.sumsq, 8 * n_local, opt.r, opt.T)
+    assert math.isclose(fin.price, shard.price, rel_tol=1e-12) and math.isclose(fin.std_err, shard.std_err / math.sqrt(8), rel_tol=1e-6)
+
+
 def test_full_size_config3_properties(ctx):
     # config 3: 100M paths x 252 steps fp32 stored step-major (100.8 GB).  Properties: checksum of the last row
     # equals the in-register kernel's payoff sum; each row's mean follows S0 e^{r t}; nothing non-finite.

@@ -11,7 +11,7 @@
 // memory pipeline has.  The path-major layout stays available for callers that need the
 // reference's indexing (CSV dump, small tests); it is not the fast path.
 //
-// Same Philox counters as price.hip (subsequence = global path id), so a stored trajectory's
+// Same Philox counters and the same exponent arithmetic as price_impl.hpp (subsequence = global path id), so a stored trajectory's
 // last row is bit-identical to the in-register path's terminal price.
 // Algorithmic HBM traffic: sizeof(T) bytes per path-step (+4 with counts) + sizeof(T) per path
 // payoff; no reads.  This is the bandwidth-bound configuration (BASELINE config 3).

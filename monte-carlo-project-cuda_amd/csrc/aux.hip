@@ -12,7 +12,8 @@ namespace mcamd {
 // (array overloads), inc/trajectories.cuh:14-52; this is the deterministic parity path (its CPU
 // twin is inc/testing.cuh:75-91).  A wavefront stages a 64-path x 128-byte tile through LDS:
 // global reads are row-contiguous (one full 128 B line per path row), LDS reads are column-wise
-// (lane = path) with a +1 pad so the lanes of a group hit different banks.
+// (lane = path); rows are padded by one 16-byte vector so that 16-byte reads of consecutive rows fall on
+// different banks.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 struct ArrayArgs {
@@ -30,7 +31,8 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
     constexpr int kWaves = kBlock / kWave;
     constexpr int TS = 128 / sizeof(T);        // tile width in steps: one 128 B line per path row
     constexpr int kRowsPerLoad = kWave / TS;   // path rows one wave-wide load covers
-    __shared__ T tile[kWaves][kWave][TS + 1];
+    constexpr int kPad = 16 / sizeof(T);       // one 16-byte vector of padding: rows stay 16-byte aligned
+    __shared__ alignas(16) T tile[kWaves][kWave][TS + kPad];
     const StepConsts<T> &c = a.c;
     const MathCtx<T> m = MathCtx<T>::init();
     const int lane = threadIdx.x & (kWave - 1);
@@ -40,28 +42,39 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
     const uint64_t wave_stride = static_cast<uint64_t>(gridDim.x) * kWaves;
     double s = 0.0, s2 = 0.0;
 
+    // VEC staging geometry: V elements (16 bytes) per lane per load, 8 lanes per path row, 8 rows per load
+    constexpr int V = 16 / sizeof(T);
+    constexpr int kLanesPerRow = TS / V;
+    constexpr int kRowsPerVecLoad = kWave / kLanesPerRow;
+    constexpr int kVecLoads = kWave / kRowsPerVecLoad;  // wave-wide loads per 64-path x TS-step tile
+    using VT = T __attribute__((ext_vector_type(V)));
+    const int vrow = lane / kLanesPerRow, vcol = (lane % kLanesPerRow) * V;
+
     for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * kWaves + wave; t < n_tiles; t += wave_stride) {
         const uint64_t path0 = t * kWave;
         const uint64_t my_path = path0 + lane;
         T St = c.S_start;
         int32_t count = c.Ik;
+        // VEC: the next tile's global loads are issued into registers before the current tile is consumed, so a
+        // wave always has loads in flight underneath its own (serially dependent) step loop
+        VT pre[kVecLoads];
+        auto prefetch = [&](uint32_t s0) {
+#pragma unroll
+            for (int i = 0; i < kVecLoads; ++i) {
+                const uint64_t p = path0 + i * kRowsPerVecLoad + vrow;
+                const bool ok = p < a.n_local && s0 + static_cast<uint32_t>(vcol) < c.n_sim;
+                const uint64_t off = ok ? p * c.n_sim + s0 + vcol : 0;   // lanes past the end re-read element 0
+                pre[i] = *reinterpret_cast<const VT *>(a.normals + off);
+            }
+        };
+        if (VEC) prefetch(0);
         for (uint32_t s0 = 0; s0 < c.n_sim; s0 += TS) {
             const uint32_t n_cols = (c.n_sim - s0 < static_cast<uint32_t>(TS)) ? c.n_sim - s0 : TS;
             // stage: global reads are contiguous along a path's row, LDS holds [path][step]
             if (VEC) {
-                constexpr int V = 16 / sizeof(T);        // elements per lane per load
-                constexpr int kLanesPerRow = TS / V;     // 8
-                constexpr int kRowsPerVecLoad = kWave / kLanesPerRow;
-                using VT = T __attribute__((ext_vector_type(V)));
-                const int vrow = lane / kLanesPerRow, vcol = (lane % kLanesPerRow) * V;
-                for (int r = 0; r < kWave; r += kRowsPerVecLoad) {
-                    const uint64_t p = path0 + r + vrow;
-                    if (p < a.n_local && static_cast<uint32_t>(vcol) < n_cols) {
-                        const VT v = *reinterpret_cast<const VT *>(a.normals + p * c.n_sim + s0 + vcol);
 #pragma unroll
-                        for (int k = 0; k < V; ++k) tile[wave][r + vrow][vcol + k] = v[k];
-                    }
-                }
+                for (int i = 0; i < kVecLoads; ++i)   // one ds_write_b128 per staged load
+                    *reinterpret_cast<VT *>(&tile[wave][i * kRowsPerVecLoad + vrow][vcol]) = pre[i];
             } else {
                 for (int r = 0; r < kWave; r += kRowsPerLoad) {
                     const uint64_t p = path0 + r + lrow;
@@ -72,7 +85,23 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (my_path < a.n_local) {
+            if (VEC && s0 + TS < c.n_sim) prefetch(s0 + TS);
+            if (VEC) {
+                // the lane's TS normals come back as TS / V 16-byte LDS reads; the step loop is fully unrolled
+                VT zz[TS / V];
+#pragma unroll
+                for (int i = 0; i < TS / V; ++i) zz[i] = *reinterpret_cast<const VT *>(&tile[wave][lane][i * V]);
+                if (my_path < a.n_local) {
+#pragma unroll
+                    for (int i = 0; i < TS / V; ++i)
+#pragma unroll
+                        for (int k = 0; k < V; ++k)
+                            if (static_cast<uint32_t>(i * V + k) < n_cols) {
+                                St = gbm_step(St, zz[i][k], c, m);
+                                if (WINDOW) count += (c.B > St) ? 1 : 0;
+                            }
+                }
+            } else if (my_path < a.n_local) {
                 for (uint32_t j = 0; j < n_cols; ++j) {
                     St = gbm_step(St, tile[wave][lane][j], c, m);
                     if (WINDOW) count += (c.B > St) ? 1 : 0;

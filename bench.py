@@ -312,9 +312,10 @@ def main():
             if free > n3 * s3 * 4 + (4 << 30):
                 buf = torch.empty(n3 * s3, dtype=torch.float32, device="cuda")
                 sim3 = capi.make_sim(n3, s3, capi.F32, 1234)
-                ctx.simulate_trajectories(opt, sim3, buf)
+                for _ in range(2):   # first touches of a fresh 100.8 GB allocation are slower
+                    ctx.simulate_trajectories(opt, sim3, buf)
                 ks = []
-                for _ in range(3):
+                for _ in range(5):
                     r3 = ctx.simulate_trajectories(opt, sim3, buf)
                     ks.append(r3.kernel_ms)
                 kms = sum(ks) / len(ks)
@@ -323,6 +324,7 @@ def main():
                 line["roofline_store"] = {
                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                     "traffic": pmc_traffic_bytes("store_kernel<float"), "kernel": "store_kernel<float,false,STEP_MAJOR,vec>", "kernel_ms": kms,
+                    "kernel_ms_min": min(ks), "launches": len(ks),
                     "workload": "BASELINE configs[2]: 100M paths x 252 steps fp32 stored step-major",
                     "algorithmic_bytes_per_launch": nbytes, "paths_per_s": n3 / (kms / 1e3),
                     "price": r3.price, "std_err": r3.std_err, "abs_err_vs_bs": abs(r3.price - BS_EXACT)}

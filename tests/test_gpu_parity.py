@@ -135,8 +135,8 @@ def test_bulk_normals_moments_large(ctx):
 
 
 # ---------------- in-register pricing vs oracle ----------------
-CASES = [  # n_paths, n_steps
-    (1, 1), (2, 1), (255, 1), (256, 1), (257, 3), (100_000, 1), (4097, 7), (5000, 252), (3000, 100), (777, 2), (513, 253)]
+CASES = [  # n_paths, n_steps; (1_000_000, 1) is BASELINE configs[0]'s shape (1M paths, one exact step)
+    (1, 1), (2, 1), (255, 1), (256, 1), (257, 3), (100_000, 1), (1_000_000, 1), (4097, 7), (5000, 252), (3000, 100), (777, 2), (513, 253)]
 
 
 @pytest.mark.parametrize("prec", [capi.F32, capi.F64])

@@ -516,6 +516,25 @@ def test_nmc_fused_equals_two_launch_route(ctx, prec, layout, n_paths):
     assert math.isclose(ra.sum, rb.sum, rel_tol=1e-12, abs_tol=1e-12) and rb.n == n_paths * n_steps
 
 
+@pytest.mark.parametrize("n_inner", [1, 63, 64, 65, 257, 1000])
+def test_nmc_inner_ragged_inner_counts(ctx, oracle, n_inner):
+    # inner-path counts that do not fill a wavefront (or a block) evenly; also exercises N_PATHS_INNER > 256, where the
+    # reference's carry-over defect would show
+    n_paths, n_steps = 3, 6
+    opt = capi.make_option(**BENCH, B=103.0, P1=0, P2=4, use_window=1)
+    traj, cnt = dev(n_paths * n_steps, torch.float64), dev(n_paths * n_steps, torch.int32)
+    ctx.simulate_trajectories(opt, capi.make_sim(n_paths, n_steps, capi.F64, seed=1234), traj, cnt)
+    inner = capi.make_sim(n_paths, n_steps, capi.F64, seed=1235, n_paths_inner=n_inner)
+    p = oparams(oracle, opt, inner)
+    T_, C_ = traj.view(n_steps, n_paths).cpu().numpy(), cnt.view(n_steps, n_paths).cpu().numpy()
+    want = np.array([[oracle.nmc_point(p, 64, q * n_steps + s_, s_, float(T_[s_, q]), int(C_[s_, q]))
+                      for q in range(n_paths)] for s_ in range(n_steps)])
+    for variant in (capi.NMC_WAVE_PER_POINT, capi.NMC_BLOCK_PER_POINT):
+        out = dev(n_paths * n_steps, torch.float64)
+        ctx.nmc_inner(opt, inner, traj, cnt, out, capi.STEP_MAJOR, variant)
+        assert np.allclose(out.view(n_steps, n_paths).cpu().numpy(), want, rtol=1e-11, atol=1e-12), variant
+
+
 def test_nmc_variants_agree_and_european_window(ctx):
     # P1=0, P2=N_STEPS, B=0: deterministic work count variant (SURVEY 8d cfg 4); both strategies agree
     n_paths, n_steps, n_inner = 64, 12, 1000

@@ -1,46 +1,51 @@
-// hello.cpp — the reference's main driver (hello.cu:3-48) re-created on the shim: same parameters,
-// same order of calls, same printed labels.  Build: make -C examples ; run on an MI355X.
-// No cudaMemcpyToSymbol step is needed (hello.cu:22): parameters travel with each call.
+// hello.cpp — what the reference's main driver does (hello.cu:3-48: the default option, CPU pricers, the three
+// GPU pricers, the three nested-MC strategies, the closed form), expressed on the shim.  Same defaults, same
+// wrapper functions, same printed labels; no cudaMemcpyToSymbol step (hello.cu:22) because parameters travel
+// with each call.  Build: make -C examples ; run on an MI355X.
 #include "monte_carlo.hpp"
+
+#include <array>
+
+namespace {
+
+// hello.cu:5-17 — S0, T, K, r, v, B, P1, P2, N_PATHS, N_PATHS_INNER, N_STEPS, step
+OptionData default_option()
+{
+    OptionData od{100.0f, 1.0f, 100.0f, 0.1f, 0.2f, 120.0f, 10, 50, 100000, 1000, 100, 0.0f};
+    od.step = od.T / static_cast<float>(od.N_STEPS);
+    return od;
+}
+
+using SingleLevel = float (*)(OptionData, int);
+using Nested = float (*)(OptionData, int, int);
+
+}  // namespace
 
 int main()
 {
-    OptionData option_data;
-    option_data.S0 = 100.0f;
-    option_data.T = 1.0f;
-    option_data.K = 100.0f;
-    option_data.r = 0.1f;
-    option_data.v = 0.2f;
-    option_data.B = 120.0f;
-    option_data.P1 = 10;
-    option_data.P2 = 50;
-    option_data.N_PATHS = 100000;
-    option_data.N_PATHS_INNER = 1000;
-    option_data.N_STEPS = 100;
-    option_data.step = option_data.T / static_cast<float>(option_data.N_STEPS);
+    const OptionData od = default_option();
+    constexpr int kThreadsPerBlock = 1024;   // accepted and ignored by the engine (hello.cu:19)
+    constexpr int kBlocks = 5000;            // likewise (hello.cu:38-40)
 
-    const int threadsPerBlock = 1024;
-
-    printOptionData(option_data);
+    printOptionData(od);
     getDeviceProperty();
 
-    wrapper_cpu_option_vanilla(option_data, threadsPerBlock);
-    wrapper_cpu_bullet_option(option_data, threadsPerBlock);
+    const std::array<SingleLevel, 5> single = {wrapper_cpu_option_vanilla, wrapper_cpu_bullet_option,
+                                               wrapper_gpu_option_vanilla, wrapper_gpu_bullet_option,
+                                               wrapper_gpu_bullet_option_atomic};
+    for (SingleLevel price : single) price(od, kThreadsPerBlock);
 
-    wrapper_gpu_option_vanilla(option_data, threadsPerBlock);
-    wrapper_gpu_bullet_option(option_data, threadsPerBlock);
-    wrapper_gpu_bullet_option_atomic(option_data, threadsPerBlock);
+    const std::array<Nested, 3> nested = {wrapper_gpu_bullet_option_nmc_one_point_one_block,
+                                          wrapper_gpu_bullet_option_nmc_one_kernel,
+                                          wrapper_gpu_bullet_option_nmc_optimal};
+    for (Nested price : nested) price(od, kThreadsPerBlock, kBlocks);
 
-    wrapper_gpu_bullet_option_nmc_one_point_one_block(option_data, threadsPerBlock, 5000);
-    wrapper_gpu_bullet_option_nmc_one_kernel(option_data, threadsPerBlock, 5000);
-    wrapper_gpu_bullet_option_nmc_optimal(option_data, threadsPerBlock, 5000);
+    float closed_form = 0.0f;
+    black_scholes_CPU(closed_form, od.S0, od.K, od.T, od.r, od.v);
+    std::cout << "\ncall Black Scholes : " << closed_form << std::endl;
 
-    float callResult = 0.0f;
-    black_scholes_CPU(callResult, option_data.S0, option_data.K, option_data.T, option_data.r, option_data.v);
-    std::cout << std::endl << "call Black Scholes : " << callResult << std::endl;
-
-    // new: fp64 paths with a confidence interval
-    const mcamd_result r = wrapper_gpu_option_vanilla_f64(option_data, 1);
+    // beyond the reference: fp64 paths with a standard error and a confidence interval
+    const mcamd_result r = wrapper_gpu_option_vanilla_f64(od, 1);
     std::cout << "fp64 vanilla : " << r.price << " +- " << r.std_err << "  95% CI [" << r.ci_lo << ", " << r.ci_hi
               << "]" << std::endl;
     return 0;

@@ -364,7 +364,11 @@ def main():
     if world == 1 and wl == "european252" and not args.no_accuracy_demo:
         n_acc = 100_000_000_000
         t_acc = time.perf_counter()
-        ra = ctx.price_paths(opt, capi.make_sim(n_acc, 1, capi.F64, 1234))
+        # priced through the barrier-window instantiation with the window wide open (B = 0: the count stays 0 and
+        # always pays) — the same European payoff, but a kernel symbol of its own, so a profile of this command
+        # keeps the headline kernel's statistics separate from this 1e11-path launch
+        opt_acc = capi.make_option(**OPTION, B=0.0, P1=0, P2=1, use_window=1)
+        ra = ctx.price_paths(opt_acc, capi.make_sim(n_acc, 1, capi.F64, 1234))
         line["accuracy_demo"] = {"workload": "European call, 1e11 paths x 1 exact step, fp64, in-register",
                                  "paths": n_acc, "price": ra.price, "std_err": ra.std_err,
                                  "abs_err_vs_bs": abs(ra.price - BS_EXACT), "within_1e-4": abs(ra.price - BS_EXACT) <= 1e-4,

@@ -8,7 +8,7 @@ R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$R/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH=(python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-accuracy-demo)
+BENCH=(python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- "${BENCH[@]}" > "$OUT/trace.log" 2>&1 \
  && timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- "${BENCH[@]}" > "$OUT/pmc_sq.log" 2>&1 \
  && timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/pmc_sq2" -- "${BENCH[@]}" > "$OUT/pmc_sq2.log" 2>&1 \

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     for key in ("price_kernel<double, false, false, 0>", "price_kernel<double, false, true, 0>",
-                "price_kernel<double, false, false, 3>", "price_kernel<float, false, false, 0>",
+                "price_kernel<double, false, false, 3>", "price_kernel<double, true, false, 0>",
+                "price_kernel<float, false, false, 0>",
                 "store_kernel<float, false, 0, true>", "final_reduce_kernel"):
         if key in name:
             return key

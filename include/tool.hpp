@@ -118,7 +118,7 @@ inline void getDeviceProperty()
     }
     const double GIGA = 1024.0 * 1024.0 * 1024.0;
     std::printf("The number of devices available is %d GPUs \n", di.device_count);
-    std::printf("Name: %s (%s)\n", di.name, di.arch);
+    std::printf("Name: %s (%s)\n", di.name[0] ? di.name : "AMD GPU", di.arch);  // the marketing name needs libdrm's id table
     std::printf("Global memory size in bytes: %fGB (free %fGB)\n", di.total_mem / GIGA, di.free_mem / GIGA);
     std::printf("LDS size per block: %d\n", di.lds_per_block);
     std::printf("Number of registers per block: %d\n", di.regs_per_block);

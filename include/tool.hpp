@@ -5,6 +5,7 @@
 //   getDeviceProperty              inc/tool.cuh:56-88   (hipDeviceProp via mcamd_get_device_info)
 //   simulateOptionPriceCPU         inc/tool.cuh:104-130 (serial CPU MC, one exact step)
 //   simulateBulletOptionPriceCPU   inc/tool.cuh:133-173 (serial CPU MC, N_STEPS steps + window)
+//   CHECK_MALLOC                   inc/tool.cuh:47-53
 //   get_max_blocks                 inc/tool.cuh:176-188
 //   isPow2 / nextPow2              inc/tool.cuh:200-210
 // setup_kernel (inc/tool.cuh:192-195) has no counterpart: the engine's Philox counters live in
@@ -18,6 +19,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <iostream>
 #include <random>
 
@@ -36,6 +38,18 @@ struct OptionData {
     float step;
 };
 static_assert(sizeof(OptionData) == 48, "OptionData must keep the reference's 48-byte layout");
+
+// Host allocation check with the reference's name and behaviour (inc/tool.cuh:47-53): message + exit.  It guards
+// the CALLER's own malloc results; the engine itself never exits (errors come back as status codes).
+#ifndef CHECK_MALLOC
+#define CHECK_MALLOC(ptr)                                                                                  \
+    do {                                                                                                   \
+        if ((ptr) == NULL) {                                                                               \
+            std::fprintf(stderr, "Memory allocation failed for %s at %s:%d\n", #ptr, __FILE__, __LINE__); \
+            std::exit(EXIT_FAILURE);                                                                       \
+        }                                                                                                  \
+    } while (0)
+#endif
 
 namespace mcamd_shim {
 

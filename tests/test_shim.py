@@ -34,6 +34,16 @@ def test_shim_headers_cite_reference_lines():
         assert re.search(r"inc/\w+\.(cuh|hpp)", text) and re.search(r":\d+-\d+", text), h
 
 
+def test_every_shim_header_is_self_contained(tmp_path):
+    # each public header must compile on its own (plain g++, C and C++ where it applies)
+    inc = os.path.join(ROOT, "include")
+    for h in sorted(os.listdir(inc)):
+        src = tmp_path / ("use_" + h.replace(".", "_") + (".c" if h.endswith(".h") else ".cpp"))
+        src.write_text(f'#include "{h}"\nint main(void) {{ return 0; }}\n')
+        cc = ["gcc", "-std=c11"] if h.endswith(".h") else ["g++", "-std=c++17"]
+        subprocess.check_call(cc + ["-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + inc, str(src)])
+
+
 @pytest.mark.gpu
 def test_hello_runs_and_prices_are_sane(built):
     out = subprocess.run([os.path.join(built, "hello")], capture_output=True, text=True, timeout=600)

@@ -46,7 +46,7 @@ PEAK_HBM_GBS = 8000.0
 W_SLOTS = {"price_f64": None, "price_f32": None}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -64,7 +64,10 @@ def parse():
     ap.add_argument("--no-store-roofline", action="store_true")
     ap.add_argument("--no-accuracy-demo", action="store_true")
     ap.add_argument("--cpu-sample-paths", type=int, default=0)
-    return ap.parse_args()
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launcher test only: spawn the ranks, rendezvous, shard and all-reduce the path counts, price "
+                         "nothing (needs no GPU); the line carries value null and \"rehearsal\": true")
+    return ap.parse_args(argv)
 
 
 def load_w_slots():
@@ -128,8 +131,114 @@ def cpu_baseline(n_steps: int, sample_paths: int):
     return out
 
 
-def main():
-    args = parse()
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(argv, n_ranks: int, port: int):
+    """The child command a bare `bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) runs: the driver's own
+    multi-rank form, one fresh process per GPU.  `argv` is this process's argument list, passed through unchanged."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(args, argv) -> int:
+    """Bare `python bench.py --gpus N`: start N rank processes and relay rank 0's JSON line.  Runs BEFORE anything
+    in this process touches the GPU (torch.cuda.device_count() does not initialise it on this image), and starts
+    the ranks as children — the parent never execs and never makes a HIP call."""
+    import subprocess
+    need_devices = args.backend == "nccl" and not args.rehearse_launch
+    if need_devices:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs for the RCCL path, found {have} "
+                  "(use --backend gloo to rehearse the multi-rank control flow on fewer GPUs)", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = launcher_command(argv, args.gpus, free_port())
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if proc.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: the {args.gpus}-rank child exited with {proc.returncode} and printed {len(lines)} JSON line(s)",
+              file=sys.stderr)
+        return proc.returncode or 1
+    print(lines[0])
+    return 0
+
+
+def rehearse(args, world: int, rank: int):
+    """--rehearse-launch: launcher + rendezvous + sharding + the one all-reduce, with path COUNTS in place of payoff
+    sums.  No kernel runs and nothing is priced; it exists so that the multi-rank launch path has a test on a box
+    with no GPU (tests/test_bench_contract.py)."""
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module("monte-carlo-project-cuda_amd")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    n_total = args.global_paths or (args.paths or 10_000_000) * world
+    lo, n_local = pkg.sharding.shard_range(n_total, world, rank) if args.global_paths else (rank * (n_total // world), n_total // world)
+    rec = torch.tensor([float(n_local), float(lo), 1.0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(rec)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "MC paths/sec, European call (price error vs closed-form BS reported)", "value": None,
+                          "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "rehearsal": True, "ranks_seen": int(rec[2].item()), "paths_covered": int(rec[0].item()),
+                          "config": {"workload": workload_name(args.workload, n_total // world, n_total, world,
+                                                               bool(args.global_paths)),
+                                     "global_paths": n_total}}))
+
+
+def workload_name(wl: str, per_gpu: int, n_total: int, world: int, strong: bool) -> str:
+    """config.workload, from the numbers actually run (BASELINE config named only when the shape is that config's)."""
+    def cnt(n):
+        for div, suf in ((1_000_000_000, "B"), (1_000_000, "M"), (1_000, "k")):
+            if n >= div and n % div == 0:
+                return f"{n // div}{suf}"
+        return str(n)
+    if wl == "european252":
+        if strong:
+            tag = " (BASELINE configs[4])" if n_total == 1_000_000_000 else ""
+            return f"European call, {cnt(n_total)} paths x 252 steps, fp64, in-register, path-sharded across {world} GPU(s){tag}"
+        tag = " (BASELINE configs[1])" if per_gpu == 10_000_000 else ""
+        return f"European call, {cnt(per_gpu)} paths/GPU x 252 steps, fp64, in-register{tag}"
+    if wl == "european252_f32":
+        return f"European call, {cnt(per_gpu)} paths/GPU x 252 steps, fp32, in-register"
+    if wl == "vanilla1":
+        return f"European call, {cnt(per_gpu)} paths/GPU x 1 exact step, fp64, in-register"
+    if wl == "store":
+        tag = " (BASELINE configs[2])" if per_gpu == 100_000_000 else ""
+        return f"European call, {cnt(per_gpu)} paths/GPU x 252 steps, fp32, trajectories stored step-major{tag}"
+    tag = " (BASELINE configs[3])" if per_gpu == 65_536 else ""
+    return f"nested MC, {cnt(per_gpu)} outer paths/GPU x 252 steps x 1000 inner, fp64{tag}"
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, argv))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        args.gpus = world   # launched by torch.distributed.run: the launcher's world size is authoritative
+    if args.rehearse_launch:
+        return rehearse(args, world, rank)
+
     import torch
     import torch.distributed as dist
 
@@ -137,13 +246,6 @@ def main():
     capi = pkg.capi
     load_w_slots()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     device_index = local_rank % torch.cuda.device_count()   # == local_rank on a node with one GPU per rank
@@ -259,11 +361,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.global_paths else "weak", "vs_baseline": None,
             "dtype": "f32" if prec == capi.F32 else "f64", "data": "synthetic",
-            "config": {"workload": {"european252": "European call, 10M paths/GPU x 252 steps, fp64, in-register (BASELINE configs[1])",
-                                    "european252_f32": "European call, 252 steps, fp32, in-register",
-                                    "vanilla1": "European call, 1 exact step, fp64, in-register",
-                                    "store": "European call, 100M paths x 252 steps, fp32, trajectories stored step-major (BASELINE configs[2])",
-                                    "nmc": "nested MC, outer paths x 252 steps x 1000 inner, fp64 (BASELINE configs[3] shape)"}[wl],
+            "config": {"workload": workload_name(wl, per_gpu, n_total, world, bool(args.global_paths)),
                        "paths_per_gpu": per_gpu, "n_steps": n_steps, "global_paths": n_total,
                        "sharding": f"path-id ranges over {world} rank(s), one {args.backend} all-reduce of (sum,sumsq,n) per step"
                        if world > 1 else "single GPU", "seed": "1234+step", "rng": "Philox4x32-10, subsequence = global path id"},

@@ -17,6 +17,62 @@ def test_bench_help_runs_without_gpu():
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
 
 
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_launcher_command_is_the_drivers_multi_rank_form():
+    b = _bench_module()
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5", "--global-paths", "1000000000"]
+    cmd = b.launcher_command(argv, 8, 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                      # the caller's flags reach every rank unchanged
+
+
+def test_workload_names_follow_the_numbers_run():
+    b = _bench_module()
+    assert "BASELINE configs[1]" in b.workload_name("european252", 10_000_000, 10_000_000, 1, False)
+    assert "BASELINE configs[1]" not in b.workload_name("european252", 1_000_000, 1_000_000, 1, False)
+    s = b.workload_name("european252", 125_000_000, 1_000_000_000, 8, True)
+    assert "1B paths" in s and "8 GPU" in s and "configs[4]" in s and "configs[1]" not in s
+    assert "configs[2]" in b.workload_name("store", 100_000_000, 100_000_000, 1, False)
+    assert "configs[3]" in b.workload_name("nmc", 65_536, 65_536, 1, False)
+
+
+def test_bare_gpus_2_self_launches_two_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent spawns 2 ranks (torch.distributed.run, 127.0.0.1),
+    they rendezvous, shard the global path range and all-reduce once; rank 0's single JSON line is relayed.
+    --rehearse-launch prices nothing, so this runs on a box with no GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--backend", "gloo", "--rehearse-launch", "--global-paths", "1000000001"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["paths_covered"] == 1_000_000_001
+    assert d["steps"] == 4 and d["warmup"] == 1 and d["rehearsal"] is True and d["value"] is None
+
+
+def test_bare_gpus_n_fails_loudly_without_n_devices():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "visible GPUs" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
 @pytest.mark.gpu
 def test_bench_emits_one_json_line_with_roofline_and_cpu_baseline():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",

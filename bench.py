@@ -2,23 +2,28 @@
 """Benchmark driver.  `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
 
 A "step" is one pass of the hot path over one batch: every rank prices its shard of a European
-call (S0=K=100, T=1, r=0.1, sigma=0.2 — hello.cu:6-10) through the C ABI (mcamd_price_paths):
+call (S0=K=100, T=1, r=0.1, sigma=0.2 — hello.cu:6-10) through the C ABI (mcamd_price_paths_enqueue):
 Philox RNG -> 252 GBM steps -> payoff -> fp64 (sum, sumsq), nothing stored — BASELINE.json
-configs[1] (10M paths, 252 steps, fp64, in-register) per GPU.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) the global job is N x 10M paths sharded by contiguous
-global path id, and each step ends with ONE all-reduce of the 6-double statistics record over RCCL,
-enqueued on the same stream (mcamd_price_paths_enqueue): no host round trip per step; weak scaling.
-Inputs are a handful of scalars, so nothing crosses PCIe in the timed region.
+configs[1] (10M paths, 252 steps, fp64, in-register) per GPU.  With N > 1 the global job is N x 10M
+paths (or --global-paths, e.g. 1e9 = configs[4]) sharded by contiguous global path id, and each step ends
+with ONE all-reduce of the 6-double statistics record over RCCL, enqueued behind the kernel on the same
+stream: no host round trip per step.  Inputs are a handful of scalars, so nothing crosses PCIe in the
+timed region.  A bare `--gpus N` (no WORLD_SIZE in the environment) starts the N ranks itself.
 
-Extra objects on the line:
-  roofline      the dominant kernel (price_kernel<double,false>) against the VALU issue roofline
-                (this path has ~zero HBM traffic and no matrix work), from HIP events recorded
-                inside the library on the launch stream;
-  roofline_store  one untimed pass of BASELINE configs[2] (100M paths x 252 steps fp32 stored
-                step-major, 101.2 GB) against the HBM roofline — the bandwidth-bound path;
-  cpu_baseline  the reference's own CPU Monte Carlo (oracle/_ref, kind "reference") or the oracle
-                port, timed on this host on a bounded sample of the same workload, rank 0, N=1 only.
-Other workloads: --workload store | nmc | vanilla1 (see --help).
+Extra objects on the line (N = 1 only, all measured in this run):
+  device          name / arch / CUs / clock / HBM total and free (mcamd_get_device_info; inc/tool.cuh:56-88,176-188)
+  roofline        the dominant kernel against the VALU issue roofline (this path has ~zero HBM traffic and no
+                  matrix work): W issue slots per path-step (counted from the ISA of the library that is loaded;
+                  refused when the count was taken from other sources) x measured path-steps/s
+  sweep           the north-star path counts 1M / 10M / 100M x {fp64, fp32}, in-register, each with kernel time,
+                  whole-call time and roofline fraction
+  roofline_store  BASELINE configs[2] (100M paths x 252 steps fp32 stored step-major + the payoff vector,
+                  101.2 GB) against the HBM roofline — the bandwidth-bound path
+  accuracy_252    "price within 1e-4 of closed form" on a 252-step BASELINE shape: 1e9 antithetic pairs with the
+                  S_T control variate, fp64
+  cfg1            BASELINE configs[0] on this host: closed form (1M evaluations) and the reference's serial MC
+  cpu_baseline    the reference's own CPU Monte Carlo (oracle/_ref) or the oracle port, timed on this host
+Other workloads: --workload store | nmc | vanilla1 | european252_f32 (see --help).
 """
 from __future__ import annotations
 
@@ -35,15 +40,14 @@ sys.path.insert(0, ROOT)
 
 BS_EXACT = 13.269676584660893  # closed form, fp64, benchmark option
 OPTION = dict(S0=100.0, T=1.0, K=100.0, r=0.1, v=0.2)
+BULLET = dict(B=120.0, P1=10, P2=50, use_window=1)     # hello.cu:11-13
 
 # VALU issue roofline (MI355X_MICROARCH.md): 256 CUs x 4 SIMD-32 x 2.4 GHz; a wave64 VALU
 # instruction issues in 2 cycles at full rate -> 32 lane-ops / cycle / SIMD.
 PEAK_VALU_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 78.6 Tlane-op/s (= 157.3 TFLOP/s fp32 FMA / 2)
 PEAK_HBM_GBS = 8000.0
 
-# Full-rate-equivalent VALU issue slots per path-step of the shipped kernels, counted from the
-# gfx950 ISA of the inner loop (profiles/isa_r01.md explains the count and the rate weights).
-W_SLOTS = {"price_f64": None, "price_f32": None}
+METRIC = "MC paths/sec, European call (price error vs closed-form BS reported)"
 
 
 def parse(argv=None):
@@ -60,9 +64,15 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
                          "multi-rank control flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--nmc-window", default="bullet", choices=["bullet", "european"],
+                    help="nested MC: the reference's bullet window B=120, P1=10, P2=50 (hello.cu:11-13), or the "
+                         "European-window variant (B=0, P2=N_STEPS) whose work count is deterministic")
+    ap.add_argument("--nmc-strategy", default="wave", choices=["wave", "block", "fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-store-roofline", action="store_true")
-    ap.add_argument("--no-accuracy-demo", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--accuracy-pairs", type=int, default=1_000_000_000)
     ap.add_argument("--cpu-sample-paths", type=int, default=0)
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher test only: spawn the ranks, rendezvous, shard and all-reduce the path counts, price "
@@ -70,67 +80,9 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
-def load_w_slots():
-    path = os.path.join(ROOT, "profiles", "valu_slots.json")
-    if os.path.exists(path):
-        with open(path) as f:
-            W_SLOTS.update(json.load(f))
-
-
-def pmc_traffic_bytes(kernel_key: str):
-    """HBM bytes per launch of a kernel from the committed PMC digest (profiles/*_pmc_per_kernel.json, produced by
-    tools/profile.sh: separate WRITE_SIZE and FETCH_SIZE passes over this same command).  WRITE_SIZE is in KB and
-    exact for 16 B-per-lane stores; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128 B requests at
-    64 B).  None when no digest has been committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.json")))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        d = json.load(f)
-    for k, v in d.items():
-        if kernel_key in k and "WRITE_SIZE" in v and "FETCH_SIZE" in v:
-            return (v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024.0
-    return None
-
-
-def cpu_baseline(n_steps: int, sample_paths: int):
-    """Times the CPU path on this host: reference build if present, else the oracle port."""
-    from oracle import pyoracle as o
-    out = {}
-    ref = o.ref_cpumc()
-    cores_avail = os.cpu_count() or 1
-    if ref is not None:
-        n = sample_paths or (2_000_000 if n_steps > 1 else 50_000_000)
-        t0 = time.perf_counter()
-        if n_steps > 1:
-            # reference CPU multi-step pricer with the barrier window wide open = European call
-            price = ref.ref_simulateBulletOptionPriceCPU(100.0, 1.0, 100.0, 0.1, 0.2, 0.0, 0, n_steps, n, n_steps)
-        else:
-            price = ref.ref_simulateOptionPriceCPU(100.0, 1.0, 100.0, 0.1, 0.2, n)
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {
-            "value": n / dt, "unit": "paths/s", "cores": 1, "kind": "reference",
-            "sample": f"{n} paths x {n_steps} steps, fp32, mt19937, reference inc/tool.cuh:"
-                      f"{'133-173' if n_steps > 1 else '104-130'} compiled as oracle/_ref, {dt:.1f} s",
-            "price": float(price), "host_cores_available": cores_avail}
-    threads = o.max_threads()
-    n = sample_paths or (threads * 150_000 if n_steps > 1 else 20_000_000)
-    p = o.make_params(n_paths=n, n_steps=n_steps, seed=1234)
-    t0 = time.perf_counter()
-    res = o.mc_paths(p, 64, 0, n, threads=threads)
-    dt = time.perf_counter() - t0
-    fin = o.finalize(res["sum"], res["sumsq"], n, 0.1, 1.0)
-    port = {"value": n / dt, "unit": "paths/s", "cores": threads, "kind": "port",
-            "sample": f"{n} paths x {n_steps} steps, fp64, Philox (same stream as the GPU), OpenMP, {dt:.1f} s",
-            "price": fin["price"], "host_cores_available": cores_avail}
-    if "cpu_baseline" in out:
-        out["cpu_baseline_port"] = port
-    else:
-        out["cpu_baseline"] = port
-    return out
-
-
+# ------------------------------------------------------------------------------------------------
+# launcher: bare `bench.py --gpus N`
+# ------------------------------------------------------------------------------------------------
 def free_port() -> int:
     import socket
     with socket.socket() as s:
@@ -193,7 +145,7 @@ def rehearse(args, world: int, rank: int):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "MC paths/sec, European call (price error vs closed-form BS reported)", "value": None,
+        print(json.dumps({"metric": METRIC, "value": None,
                           "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "rehearsal": True, "ranks_seen": int(rec[2].item()), "paths_covered": int(rec[0].item()),
                           "config": {"workload": workload_name(args.workload, n_total // world, n_total, world,
@@ -201,7 +153,7 @@ def rehearse(args, world: int, rank: int):
                                      "global_paths": n_total}}))
 
 
-def workload_name(wl: str, per_gpu: int, n_total: int, world: int, strong: bool) -> str:
+def workload_name(wl: str, per_gpu: int, n_total: int, world: int, strong: bool, nmc_window: str = "bullet") -> str:
     """config.workload, from the numbers actually run (BASELINE config named only when the shape is that config's)."""
     def cnt(n):
         for div, suf in ((1_000_000_000, "B"), (1_000_000, "M"), (1_000, "k")):
@@ -222,9 +174,171 @@ def workload_name(wl: str, per_gpu: int, n_total: int, world: int, strong: bool)
         tag = " (BASELINE configs[2])" if per_gpu == 100_000_000 else ""
         return f"European call, {cnt(per_gpu)} paths/GPU x 252 steps, fp32, trajectories stored step-major{tag}"
     tag = " (BASELINE configs[3])" if per_gpu == 65_536 else ""
-    return f"nested MC, {cnt(per_gpu)} outer paths/GPU x 252 steps x 1000 inner, fp64{tag}"
+    win = "bullet window B=120 P1=10 P2=50 (hello.cu:11-13)" if nmc_window == "bullet" else "European window (B=0, P2=N_STEPS)"
+    return f"nested MC, {cnt(per_gpu)} outer paths/GPU x 252 steps x 1000 inner, fp64, {win}{tag}"
 
 
+# ------------------------------------------------------------------------------------------------
+# roofline helpers
+# ------------------------------------------------------------------------------------------------
+def load_w_slots(build_id: str):
+    """ISA issue-slot counts of the shipped inner loops (tools/count_valu_slots.py, refreshed by build()).  They are
+    only valid for the sources they were counted from: a count taken from other sources than the loaded library is
+    refused (every W is None and roofline.frac is null, with the two ids in roofline.stale)."""
+    path = os.path.join(ROOT, "profiles", "valu_slots.json")
+    if not os.path.exists(path):
+        return {}, {"reason": "profiles/valu_slots.json missing"}
+    with open(path) as f:
+        d = json.load(f)
+    if d.get("build_id") != build_id:
+        return {}, {"reason": "ISA slot counts were taken from other sources than the loaded library",
+                    "library_build_id": build_id, "counts_build_id": d.get("build_id")}
+    return d, None
+
+
+def pmc_traffic_bytes(kernel_key: str):
+    """HBM bytes per launch of a kernel from the committed PMC digest (profiles/*_pmc_per_kernel.json, produced by
+    tools/profile.sh: separate WRITE_SIZE and FETCH_SIZE passes over this same command).  WRITE_SIZE is in KB and
+    exact for 16 B-per-lane stores; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128 B requests at
+    64 B).  None when no digest has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    for k, v in d.items():
+        if kernel_key in k and "WRITE_SIZE" in v and "FETCH_SIZE" in v:
+            return (v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024.0
+    return None
+
+
+def valu_roofline(W, stale, key, kernel, lane_steps_per_s, traffic_key=None, extra=None):
+    w = W.get(key)
+    rl = {"bound": "valu", "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
+          "traffic": pmc_traffic_bytes(traffic_key) if traffic_key else None, "kernel": kernel,
+          "path_steps_per_s_kernel": lane_steps_per_s, "valu_slots_per_path_step": w,
+          "achieved": lane_steps_per_s * w / 1e12 if w else None,
+          "frac": lane_steps_per_s * w / 1e12 / PEAK_VALU_TLANEOPS if w else None}
+    if stale:
+        rl["stale"] = stale
+    if extra:
+        rl.update(extra)
+    return rl
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only; the only place bench.py touches oracle/)
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(n_steps: int, sample_paths: int):
+    """Times the CPU path on this host: reference build if present, else the oracle port."""
+    from oracle import pyoracle as o
+    out = {}
+    ref = o.ref_cpumc()
+    cores_avail = os.cpu_count() or 1
+    if ref is not None:
+        n = sample_paths or (2_000_000 if n_steps > 1 else 50_000_000)
+        t0 = time.perf_counter()
+        if n_steps > 1:
+            # reference CPU multi-step pricer with the barrier window wide open = European call
+            price = ref.ref_simulateBulletOptionPriceCPU(100.0, 1.0, 100.0, 0.1, 0.2, 0.0, 0, n_steps, n, n_steps)
+        else:
+            price = ref.ref_simulateOptionPriceCPU(100.0, 1.0, 100.0, 0.1, 0.2, n)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": n / dt, "unit": "paths/s", "cores": 1, "kind": "reference",
+            "sample": f"{n} paths x {n_steps} steps, fp32, mt19937, reference inc/tool.cuh:"
+                      f"{'133-173' if n_steps > 1 else '104-130'} compiled as oracle/_ref, {dt:.1f} s",
+            "price": float(price), "host_cores_available": cores_avail}
+    threads = o.max_threads()
+    n = sample_paths or (threads * 150_000 if n_steps > 1 else 20_000_000)
+    p = o.make_params(n_paths=n, n_steps=n_steps, seed=1234)
+    t0 = time.perf_counter()
+    res = o.mc_paths(p, 64, 0, n, threads=threads)
+    dt = time.perf_counter() - t0
+    fin = o.finalize(res["sum"], res["sumsq"], n, 0.1, 1.0)
+    port = {"value": n / dt, "unit": "paths/s", "cores": threads, "kind": "port",
+            "sample": f"{n} paths x {n_steps} steps, fp64, Philox (same stream as the GPU), OpenMP, {dt:.1f} s",
+            "price": fin["price"], "host_cores_available": cores_avail}
+    if "cpu_baseline" in out:
+        out["cpu_baseline_port"] = port
+    else:
+        out["cpu_baseline"] = port
+    return out
+
+
+def cpu_cfg1(capi):
+    """BASELINE configs[0] on this host: the closed form evaluated 1M times over a (K, sigma) grid
+    (inc/BlackandScholes.hpp:34-43) and the 1M-path, 1-step serial Monte Carlo (inc/tool.cuh:104-130), one core."""
+    from oracle import pyoracle as o
+    out = {"workload": "BASELINE configs[0]: European call, 1M paths x 1 step + closed form, CPU, 1 core"}
+    ref_bs, ref_mc = o.ref_bs(), o.ref_cpumc()
+    n_eval = 1_000_000
+    if ref_bs is not None:
+        t0 = time.perf_counter()
+        chk = ref_bs.ref_black_scholes_grid(n_eval) if hasattr(ref_bs, "ref_black_scholes_grid") else None
+        dt = time.perf_counter() - t0
+        if chk is not None:
+            out["closed_form"] = {"kind": "reference", "evals": n_eval, "seconds": dt, "evals_per_s": n_eval / dt,
+                                  "checksum": float(chk), "what": "black_scholes_CPU over a 1000 x 1000 (K, sigma) grid, fp32"}
+    if "closed_form" not in out:
+        t0 = time.perf_counter()
+        chk = o.bs_call_f32_grid(n_eval)
+        dt = time.perf_counter() - t0
+        out["closed_form"] = {"kind": "port", "evals": n_eval, "seconds": dt, "evals_per_s": n_eval / dt,
+                              "checksum": float(chk), "what": "oracle_bs_call_f32 over a 1000 x 1000 (K, sigma) grid, fp32"}
+    out["closed_form"]["price_benchmark_option_f32"] = capi.bs_call_f32(100.0, 100.0, 1.0, 0.1, 0.2)
+    n = 1_000_000
+    if ref_mc is not None:
+        t0 = time.perf_counter()
+        price = ref_mc.ref_simulateOptionPriceCPU(100.0, 1.0, 100.0, 0.1, 0.2, n)
+        dt = time.perf_counter() - t0
+        out["serial_mc"] = {"kind": "reference", "paths": n, "steps": 1, "seconds": dt, "paths_per_s": n / dt,
+                            "price": float(price), "abs_err_vs_bs": abs(float(price) - BS_EXACT),
+                            "what": "simulateOptionPriceCPU (inc/tool.cuh:104-130), fp32, mt19937, unseeded, 1 core"}
+    p = o.make_params(n_paths=n, n_steps=1, seed=1234)
+    t0 = time.perf_counter()
+    res = o.mc_paths(p, 64, 0, n, threads=1)
+    dt = time.perf_counter() - t0
+    fin = o.finalize(res["sum"], res["sumsq"], n, 0.1, 1.0)
+    out["serial_mc_port_f64"] = {"kind": "port", "paths": n, "steps": 1, "seconds": dt, "paths_per_s": n / dt,
+                                 "price": fin["price"], "std_err": fin["std_err"],
+                                 "abs_err_vs_bs": abs(fin["price"] - BS_EXACT)}
+    return out
+
+
+def cpu_nmc_baseline(opt_kw, n_paths, n_steps, n_inner, traj, cnt, budget_s=12.0):
+    """Nested MC on this host, one core: oracle_nmc_point (inc/nmc.cuh:47-66,100-103 — every remaining step of every
+    inner path, as the reference runs it) on a sample of stored points spread over the steps."""
+    from oracle import pyoracle as o
+    p = o.make_params(**OPTION, B=opt_kw["B"], P1=opt_kw["P1"], P2=opt_kw["P2"], use_window=1, n_paths=n_paths,
+                      n_steps=n_steps, n_paths_inner=n_inner, seed=1235)
+    S, C = traj.view(n_steps, n_paths), cnt.view(n_steps, n_paths)
+    steps = [0, 25, 50, 100, 150, 200, 240]
+    t0 = time.perf_counter()
+    done, path_steps = 0, 0
+    q = 0
+    while time.perf_counter() - t0 < budget_s and q < 64:
+        for s_ in steps:
+            c0 = int(C[s_, q].item())
+            o.nmc_point(p, 64, q * n_steps + s_, s_, float(S[s_, q].item()), c0)
+            done += 1
+            if not (c0 > p.P2):
+                path_steps += n_inner * (n_steps - 1 - s_)
+        q += 1
+    dt = time.perf_counter() - t0
+    return {"value": done * n_inner / dt, "unit": "paths/s", "cores": 1, "kind": "port",
+            "sample": f"{done} stored points x {n_inner} inner paths (steps {steps}, {q} outer paths), fp64, "
+                      f"oracle_nmc_point = inc/nmc.cuh:47-66 restated, {dt:.1f} s",
+            "inner_path_steps_per_s": path_steps / dt, "host_cores_available": os.cpu_count() or 1}
+
+
+# ------------------------------------------------------------------------------------------------
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
@@ -244,7 +358,7 @@ def main(argv=None):
 
     pkg = importlib.import_module("monte-carlo-project-cuda_amd")
     capi = pkg.capi
-    load_w_slots()
+    W, stale = load_w_slots(capi.build_id())
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
@@ -279,23 +393,34 @@ def main(argv=None):
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ctx = capi.Context(device_index, stream.cuda_stream)
+    info = ctx.device_info()
+    device = {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": info.compute_units,
+              "wavefront_size": info.wavefront_size, "clock_mhz": info.clock_khz / 1e3,
+              "mem_clock_mhz": info.mem_clock_khz / 1e3, "mem_bus_bits": info.mem_bus_bits,
+              "hbm_total_gb": info.total_mem / 1e9, "hbm_free_gb": info.free_mem / 1e9,
+              "lds_per_block_kb": info.lds_per_block / 1024, "l2_mb": info.l2_bytes / 2**20,
+              "devices_visible": info.device_count, "library_build_id": capi.build_id()}
 
-    traj = None
-    nmc_bufs = None
+    traj = payoffs = None
+    nmc = None
     if wl == "store":
         traj = torch.empty(per_gpu * n_steps, dtype=torch.float32, device="cuda")
+        payoffs = torch.empty(per_gpu, dtype=torch.float32, device="cuda")
     if wl == "nmc":
-        n_steps, n_inner = 252, 1000
-        wopt = capi.make_option(**OPTION, B=0.0, P1=0, P2=n_steps, use_window=1)  # European-window variant
-        tr = torch.empty(per_gpu * n_steps, dtype=torch.float64, device="cuda")
-        cn = torch.empty(per_gpu * n_steps, dtype=torch.int32, device="cuda")
-        pp = torch.empty(per_gpu * n_steps, dtype=torch.float64, device="cuda")
-        nmc_bufs = (wopt, tr, cn, pp, n_inner)
+        n_inner = 1000
+        win = dict(BULLET) if args.nmc_window == "bullet" else dict(B=0.0, P1=0, P2=n_steps, use_window=1)
+        nmc = {"opt": capi.make_option(**OPTION, **win), "win": win, "n_inner": n_inner,
+               "traj": torch.empty(per_gpu * n_steps, dtype=torch.float64, device="cuda"),
+               "cnt": torch.empty(per_gpu * n_steps, dtype=torch.int32, device="cuda"),
+               "out": torch.empty(per_gpu * n_steps, dtype=torch.float64, device="cuda"),
+               "variant": {"wave": capi.NMC_WAVE_PER_POINT, "block": capi.NMC_BLOCK_PER_POINT, "fused": -1}[args.nmc_strategy]}
 
     is_price = wl in ("european252", "european252_f32", "vanilla1")
     # in-register workloads run asynchronously: each step enqueues the simulation + final reduce, then (N > 1) ONE
     # all-reduce of the 6-double stats record on the same stream; the host synchronises once, after the K steps.
     stats = torch.zeros(max(args.steps, 1) + args.warmup, 8, dtype=torch.float64, device="cuda")
+    pending = []
+    nmc_runs = []
 
     def one_step(i: int, slot: int = 0):
         seed = 1234 + i
@@ -309,19 +434,24 @@ def main(argv=None):
             return None, None
         if wl == "store":
             sim = capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu)
-            res = ctx.simulate_trajectories(opt, sim, traj)
+            res = ctx.simulate_trajectories(opt, sim, traj, None, payoffs)
         else:
-            wopt, tr, cn, pp, n_inner = nmc_bufs
-            ctx.simulate_trajectories(wopt, capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu), tr, cn)
-            res = ctx.nmc_inner(wopt, capi.make_sim(n_total, n_steps, prec, seed + 1, lo, per_gpu, n_inner), tr, cn, pp)
+            sim_o = capi.make_sim(n_total, n_steps, prec, seed, lo, per_gpu)
+            sim_i = capi.make_sim(n_total, n_steps, prec, seed + 100_003, lo, per_gpu, nmc["n_inner"])
+            if nmc["variant"] == -1:
+                res = ctx.nmc_fused(nmc["opt"], sim_i, seed, nmc["traj"], nmc["cnt"], nmc["out"])
+                outer_ms = 0.0
+            else:
+                r_o = ctx.simulate_trajectories(nmc["opt"], sim_o, nmc["traj"], nmc["cnt"])
+                res = ctx.nmc_inner(nmc["opt"], sim_i, nmc["traj"], nmc["cnt"], nmc["out"], variant=nmc["variant"])
+                outer_ms = r_o.kernel_ms
+            nmc_runs.append((res.kernel_ms, outer_ms, res.work_steps))
         if world > 1:
             s, s2, n = sharding.allreduce_stats(res.sum, res.sumsq, res.n, device=coll_device)
             fin = capi.finalize(s, s2, n, opt.r, opt.T)
         else:
             fin = res
         return res, fin
-
-    pending = []
 
     def fence():
         for w in pending:
@@ -334,6 +464,7 @@ def main(argv=None):
     for i in range(args.warmup):
         one_step(-1 - i, args.steps + i)
     fence()
+    nmc_runs.clear()
     t0 = time.perf_counter()
     kernel_ms = []
     fin = res = None
@@ -356,23 +487,41 @@ def main(argv=None):
         units = n_total * args.steps
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
         line = {
-            "metric": "MC paths/sec, European call (price error vs closed-form BS reported)",
+            "metric": METRIC,
             "value": units / elapsed, "unit": "paths/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.global_paths else "weak", "vs_baseline": None,
             "dtype": "f32" if prec == capi.F32 else "f64", "data": "synthetic",
-            "config": {"workload": workload_name(wl, per_gpu, n_total, world, bool(args.global_paths)),
+            "config": {"workload": workload_name(wl, per_gpu, n_total, world, bool(args.global_paths), args.nmc_window),
                        "paths_per_gpu": per_gpu, "n_steps": n_steps, "global_paths": n_total,
                        "sharding": f"path-id ranges over {world} rank(s), one {args.backend} all-reduce of (sum,sumsq,n) per step"
                        if world > 1 else "single GPU", "seed": "1234+step", "rng": "Philox4x32-10, subsequence = global path id"},
             "path_steps_per_s": units * n_steps / elapsed,
-            "kernel_ms_avg": avg_kernel_s * 1e3,
+            "kernel_ms_avg": avg_kernel_s * 1e3, "kernel_ms_min": min(kernel_ms), "kernel_ms_max": max(kernel_ms),
+            "device": device,
         }
         if wl == "nmc":
-            inner_steps = per_gpu * world * nmc_bufs[4] * (n_steps * (n_steps - 1) // 2)   # sum of remaining steps
-            line["inner_paths_per_s"] = per_gpu * world * n_steps * nmc_bufs[4] * args.steps / elapsed
-            line["inner_path_steps_per_s"] = inner_steps * args.steps / elapsed
+            n_inner = nmc["n_inner"]
+            k_ms = sum(r[0] for r in nmc_runs) / len(nmc_runs)
+            o_ms = sum(r[1] for r in nmc_runs) / len(nmc_runs)
+            work = sum(r[2] for r in nmc_runs) / len(nmc_runs)          # executed inner lane-steps per pass
+            inner_paths = per_gpu * world * n_steps * n_inner              # inner paths per pass (all points)
+            line["value"] = (n_total + inner_paths) * args.steps / elapsed
+            line["config"]["value_counts"] = "outer + inner paths per second (inner paths of closed-window points included: they are priced, at zero)"
+            line["config"]["strategy"] = args.nmc_strategy
+            line["config"]["window"] = nmc["win"]
+            line["inner_paths_per_s"] = inner_paths * args.steps / elapsed
+            line["executed_inner_path_steps_per_pass"] = work
+            line["executed_inner_path_steps_per_s"] = work * args.steps / elapsed
+            line["european_window_inner_path_steps"] = per_gpu * n_inner * (n_steps * (n_steps - 1) // 2)
+            line["inner_kernel_ms"] = k_ms
+            line["outer_kernel_ms"] = o_ms
             line["mean_point_price"] = fin.price
+            line["path_steps_per_s"] = None
+            # imbalance: kernel time against the time the executed steps would take at the in-register kernel's rate
+            key = "nmc_wave_f64_window"
+            line["roofline"] = valu_roofline(W, stale, key, f"nmc_{args.nmc_strategy}_kernel<double,window>",
+                                             work / (k_ms / 1e3), extra={"work": "64 lanes x steps each wavefront ran"})
         if wl != "nmc":
             line.update({"price": fin.price, "std_err": fin.std_err, "ci95": [fin.ci_lo, fin.ci_hi],
                          "bs_closed_form": BS_EXACT, "abs_err_vs_bs": abs(fin.price - BS_EXACT),
@@ -380,59 +529,78 @@ def main(argv=None):
                          "within_1e-4": abs(fin.price - BS_EXACT) <= 1e-4})
         # roofline of the dominant kernel, from the library's HIP events on the launch stream
         if wl == "store":
-            bytes_per_launch = per_gpu * n_steps * 4 + 16 * res.grid   # trajectories + block records
+            bytes_per_launch = per_gpu * n_steps * 4 + per_gpu * 4 + 16 * res.grid   # trajectories + payoffs + block records
             ach = bytes_per_launch / avg_kernel_s / 1e9
             line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic_bytes("store_kernel<float"),
                                 "kernel": "store_kernel<float,false,STEP_MAJOR,vec>",
                                 "algorithmic_bytes_per_launch": bytes_per_launch}
         elif wl in ("european252", "european252_f32"):
-            key = "price_f64" if prec == capi.F64 else "price_f32"
-            w = W_SLOTS.get(key)
-            steps_per_s = per_gpu * n_steps / avg_kernel_s
-            rl = {"bound": "valu", "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
-                  "traffic": pmc_traffic_bytes("price_kernel<double" if prec == capi.F64 else "price_kernel<float"),
-                  "kernel": f"price_kernel<{'double' if prec == capi.F64 else 'float'},false>",
-                  "path_steps_per_s_kernel": steps_per_s, "valu_slots_per_path_step": w}
-            if w:
-                rl["achieved"] = steps_per_s * w / 1e12
-                rl["frac"] = rl["achieved"] / PEAK_VALU_TLANEOPS
-            else:
-                rl["achieved"] = None
-                rl["frac"] = None
-            line["roofline"] = rl
+            f64 = prec == capi.F64
+            line["roofline"] = valu_roofline(W, stale, "price_f64" if f64 else "price_f32",
+                                             f"price_kernel<{'double' if f64 else 'float'},false>",
+                                             per_gpu * n_steps / avg_kernel_s,
+                                             "price_kernel<double" if f64 else "price_kernel<float")
+
+    solo = rank == 0 and world == 1
+
+    # the north-star sweep: 1M / 10M / 100M paths x 252 steps, in-register, both precisions.  Synchronous calls
+    # (mcamd_price_paths): kernel_ms = HIP events around the simulation kernel, call_ms = host wall time of the whole
+    # call (launches + final reduce + 16-byte copy + sync), so call_ms - kernel_ms is the per-call overhead.
+    if solo and wl == "european252" and not args.no_sweep:
+        sweep = []
+        for p_, key in ((capi.F64, "price_f64"), (capi.F32, "price_f32")):
+            for n in (1_000_000, 10_000_000, 100_000_000):
+                ks, cs = [], []
+                r_ = None
+                for rep in range(6):
+                    torch.cuda.synchronize()
+                    tc = time.perf_counter()
+                    r_ = ctx.price_paths(opt, capi.make_sim(n, 252, p_, 4321 + rep))
+                    cs.append((time.perf_counter() - tc) * 1e3)
+                    ks.append(r_.kernel_ms)
+                k, c = median(ks[1:]), median(cs[1:])
+                w = W.get(key)
+                e = {"paths": n, "steps": 252, "dtype": "f64" if p_ == capi.F64 else "f32", "kernel_ms": k, "call_ms": c,
+                     "call_over_kernel": c / k, "paths_per_s": n / (c / 1e3), "paths_per_s_kernel": n / (k / 1e3),
+                     "roofline_frac": (n * 252 / (k / 1e3)) * w / 1e12 / PEAK_VALU_TLANEOPS if w else None,
+                     "valu_slots_per_path_step": w, "price": r_.price, "std_err": r_.std_err,
+                     "abs_err_vs_bs": abs(r_.price - BS_EXACT), "within_3se": abs(r_.price - BS_EXACT) <= 3 * r_.std_err}
+                sweep.append(e)
+        line["sweep"] = sweep
 
     # bandwidth-bound path, one untimed pass of configs[2] beside the headline (N=1 only)
-    if world == 1 and wl == "european252" and not args.no_store_roofline:
+    if solo and wl == "european252" and not args.no_store_roofline:
         try:
             n3, s3 = 100_000_000, 252
             free, _ = torch.cuda.mem_get_info()
             if free > n3 * s3 * 4 + (4 << 30):
                 buf = torch.empty(n3 * s3, dtype=torch.float32, device="cuda")
+                pay = torch.empty(n3, dtype=torch.float32, device="cuda")
                 sim3 = capi.make_sim(n3, s3, capi.F32, 1234)
                 for _ in range(2):   # first touches of a fresh 100.8 GB allocation are slower
-                    ctx.simulate_trajectories(opt, sim3, buf)
+                    ctx.simulate_trajectories(opt, sim3, buf, None, pay)
                 ks = []
-                for _ in range(5):
-                    r3 = ctx.simulate_trajectories(opt, sim3, buf)
+                for _ in range(7):
+                    r3 = ctx.simulate_trajectories(opt, sim3, buf, None, pay)
                     ks.append(r3.kernel_ms)
                 kms = sum(ks) / len(ks)
-                nbytes = n3 * s3 * 4 + 16 * r3.grid
+                nbytes = n3 * s3 * 4 + n3 * 4 + 16 * r3.grid     # trajectories + payoff vector + block records: 101.2 GB
                 ach = nbytes / (kms / 1e3) / 1e9
                 line["roofline_store"] = {
                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                     "traffic": pmc_traffic_bytes("store_kernel<float"), "kernel": "store_kernel<float,false,STEP_MAJOR,vec>", "kernel_ms": kms,
                     "kernel_ms_min": min(ks), "launches": len(ks),
-                    "workload": "BASELINE configs[2]: 100M paths x 252 steps fp32 stored step-major",
+                    "workload": "BASELINE configs[2]: 100M paths x 252 steps fp32 stored step-major + the payoff vector",
                     "algorithmic_bytes_per_launch": nbytes, "paths_per_s": n3 / (kms / 1e3),
                     "price": r3.price, "std_err": r3.std_err, "abs_err_vs_bs": abs(r3.price - BS_EXACT)}
-                del buf
+                del buf, pay
         except Exception as e:  # the headline must survive a failure of the side measurement
             line["roofline_store"] = {"error": str(e)}
 
     # opt-in log-space stepping (MCAMD_FLAG_LOG_SPACE): same draws, ln(St/S0) carried instead of St.  Reported
     # beside the headline, never as the headline (the headline is the reference's recurrence as written).
-    if world == 1 and wl == "european252":
+    if solo and wl == "european252":
         ks = []
         for i in range(4):
             rl = ctx.price_paths(opt, capi.make_sim(n_total, n_steps, prec, 1234 + i, lo, per_gpu, flags=capi.FLAG_LOG_SPACE))
@@ -440,41 +608,40 @@ def main(argv=None):
         kms = sum(ks[1:]) / len(ks[1:])
         line["log_space_mode"] = {"kernel_ms": kms, "paths_per_s_kernel": per_gpu / (kms / 1e3), "price": rl.price,
                                   "std_err": rl.std_err, "abs_err_vs_bs": abs(rl.price - BS_EXACT),
-                                  "valu_slots_per_path_step": W_SLOTS.get("price_f64_logspace")}
+                                  "valu_slots_per_path_step": W.get("price_f64_logspace")}
 
-    # opt-in variance reduction on the headline workload (antithetic pairs + S_T control variate): same
-    # kernel family, reported with its own standard error.  A sample is an antithetic PAIR (2 path evaluations).
-    if world == 1 and wl == "european252":
+    # "price within 1e-4 of closed form" on a 252-step BASELINE shape: the plain estimator would need > 2.6e10 paths
+    # (sigma_payoff = 16.1), so this uses the engine's variance reduction — antithetic pairs + S_T control variate,
+    # the same kernel family — on 1e9 samples (BASELINE configs[4]'s count; a sample = one antithetic PAIR), fp64.
+    if solo and wl == "european252" and not args.no_accuracy:
         fl = capi.FLAG_ANTITHETIC | capi.FLAG_CONTROL_VARIATE
-        ks = []
-        for i in range(3):
-            rv = ctx.price_paths(opt, capi.make_sim(n_total, n_steps, prec, 1234 + i, lo, per_gpu, flags=fl))
-            ks.append(rv.kernel_ms)
-        line["variance_reduction_mode"] = {
-            "flags": "antithetic+control_variate", "samples": per_gpu, "kernel_ms": sum(ks[1:]) / 2, "price": rv.price,
-            "std_err": rv.std_err, "abs_err_vs_bs": abs(rv.price - BS_EXACT), "cv_rho": rv.cv_rho, "cv_beta": rv.cv_beta,
-            "variance_ratio_vs_plain": (fin.std_err / rv.std_err) ** 2 if rv.std_err > 0 else None}
-
-    # "price within 1e-4 of closed form": the standard error must be well under 1e-4, i.e. >= ~1e11 paths for this
-    # option (sigma_payoff = 16.1).  The exact one-step pricer (BASELINE configs[0]'s scheme on the GPU) does that
-    # in about half a second; reported beside the headline as evidence that the estimator converges to the closed
-    # form, with its own SE so the claim can be checked.
-    if world == 1 and wl == "european252" and not args.no_accuracy_demo:
-        n_acc = 100_000_000_000
+        n_acc = args.accuracy_pairs
         t_acc = time.perf_counter()
-        # priced through the barrier-window instantiation with the window wide open (B = 0: the count stays 0 and
-        # always pays) — the same European payoff, but a kernel symbol of its own, so a profile of this command
-        # keeps the headline kernel's statistics separate from this 1e11-path launch
-        opt_acc = capi.make_option(**OPTION, B=0.0, P1=0, P2=1, use_window=1)
-        ra = ctx.price_paths(opt_acc, capi.make_sim(n_acc, 1, capi.F64, 1234))
-        line["accuracy_demo"] = {"workload": "European call, 1e11 paths x 1 exact step, fp64, in-register",
-                                 "paths": n_acc, "price": ra.price, "std_err": ra.std_err,
-                                 "abs_err_vs_bs": abs(ra.price - BS_EXACT), "within_1e-4": abs(ra.price - BS_EXACT) <= 1e-4,
-                                 "within_3se": abs(ra.price - BS_EXACT) <= 3 * ra.std_err,
-                                 "seconds": time.perf_counter() - t_acc, "kernel_ms": ra.kernel_ms}
+        ra = ctx.price_paths(opt, capi.make_sim(n_acc, 252, capi.F64, 20260101, flags=fl))
+        line["accuracy_252"] = {
+            "workload": f"European call, {n_acc} antithetic pairs x 252 steps, fp64, in-register, S_T control variate",
+            "samples": n_acc, "path_evaluations": 2 * n_acc, "price": ra.price, "std_err": ra.std_err,
+            "ci95": [ra.ci_lo, ra.ci_hi], "abs_err_vs_bs": abs(ra.price - BS_EXACT),
+            "within_1e-4": abs(ra.price - BS_EXACT) <= 1e-4, "within_3se": abs(ra.price - BS_EXACT) <= 3 * ra.std_err,
+            "cv_rho": ra.cv_rho, "cv_beta": ra.cv_beta, "kernel_ms": ra.kernel_ms, "seconds": time.perf_counter() - t_acc,
+            "variance_ratio_vs_plain": (16.109 * math.exp(-0.1) / math.sqrt(n_acc) / ra.std_err) ** 2 if ra.std_err > 0 else None}
+        # and the exact one-step scheme (BASELINE configs[0]'s scheme on the GPU), plain estimator, 1e11 paths
+        opt_acc = capi.make_option(**OPTION, B=0.0, P1=0, P2=1, use_window=1)   # a kernel symbol of its own in profiles
+        t_acc = time.perf_counter()
+        r1 = ctx.price_paths(opt_acc, capi.make_sim(100_000_000_000, 1, capi.F64, 1234))
+        line["accuracy_demo"] = {"workload": "European call, 1e11 paths x 1 exact step, fp64, in-register, plain estimator",
+                                 "paths": 100_000_000_000, "price": r1.price, "std_err": r1.std_err,
+                                 "abs_err_vs_bs": abs(r1.price - BS_EXACT), "within_1e-4": abs(r1.price - BS_EXACT) <= 1e-4,
+                                 "within_3se": abs(r1.price - BS_EXACT) <= 3 * r1.std_err,
+                                 "seconds": time.perf_counter() - t_acc, "kernel_ms": r1.kernel_ms}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line.update(cpu_baseline(n_steps, args.cpu_sample_paths))
+    if solo and not args.no_cpu_baseline:
+        if wl == "nmc":
+            line["cpu_baseline"] = cpu_nmc_baseline(nmc["win"], per_gpu, n_steps, nmc["n_inner"], nmc["traj"], nmc["cnt"])
+        else:
+            line.update(cpu_baseline(n_steps, args.cpu_sample_paths))
+        if wl == "european252":
+            line["cfg1"] = cpu_cfg1(capi)
 
     ctx.close()
     if world > 1:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MCAMD_ABI_VERSION 2
+#define MCAMD_ABI_VERSION 3
 
 /* status codes */
 #define MCAMD_OK 0
@@ -93,6 +93,9 @@ typedef struct mcamd_option {
     double Sk;          /* restart: initial price; 0 means S0 (inc/trajectories.cuh:141) */
     int32_t Tk;         /* restart: steps already elapsed; n_steps - Tk are simulated */
     int32_t reserved;
+    double dt;          /* time step of the multi-step kernels, the reference's OptionData.step
+                           (inc/tool.cuh:25, read at inc/trajectories.cuh:131, inc/nmc.cuh:28); 0 = T / n_steps.
+                           The discount stays exp(-r T), as in the reference (inc/wrappers.cuh:85). */
 } mcamd_option;
 
 /* Simulation shape. The job has n_paths paths; this call simulates the shard
@@ -131,6 +134,10 @@ typedef struct mcamd_result {
     double sum_yc;     /* sum of payoff * c */
     double cv_beta;    /* sample-optimal coefficient cov(y, c) / var(c) used in price */
     double cv_rho;     /* sample correlation of payoff and control; variance shrinks by 1 - rho^2 */
+    /* nested MC (mcamd_nmc_inner / mcamd_nmc_fused), zero otherwise: inner path-steps the kernel executed, counted as
+     * 64 lanes x the steps each wavefront ran (a wavefront leaves a point's step loop as soon as every lane's barrier
+     * count is beyond P2, where the payoff can no longer be non-zero): the work figure for throughput / roofline */
+    double work_steps;
 } mcamd_result;
 
 /* Device report: replaces getDeviceProperty (inc/tool.cuh:56-88) and the free/total memory
@@ -145,6 +152,9 @@ typedef struct mcamd_device_info {
 
 int mcamd_abi_version(void);
 const char *mcamd_last_error(void);
+/* 16-hex-digit hash of the kernel sources and compile flags this library was built from; profiles/valu_slots.json
+ * (the ISA issue-slot counts bench.py prices the VALU roofline with) carries the same id when it describes this build */
+const char *mcamd_build_id(void);
 int mcamd_device_count(int *count);
 
 /* hip_stream: a hipStream_t to launch on (e.g. the caller framework's current stream), or NULL

@@ -72,12 +72,16 @@ inline mcamd_ctx *context()
     return ctx;
 }
 
-inline mcamd_option to_option(const OptionData &od, bool window)
+// multi_step: the kernels that loop over N_STEPS read the time step from OptionData.step
+// (inc/trajectories.cuh:131, inc/nmc.cuh:28), so it travels as mcamd_option.dt; the one-step vanilla pricer
+// uses T itself (inc/trajectories.cuh:58-76) and passes 0.
+inline mcamd_option to_option(const OptionData &od, bool window, bool multi_step = true)
 {
     mcamd_option o{};
     o.S0 = od.S0; o.T = od.T; o.K = od.K; o.r = od.r; o.v = od.v; o.B = od.B;
     o.P1 = od.P1; o.P2 = od.P2;
     o.use_window = window ? 1 : 0;
+    o.dt = (multi_step && od.step > 0.0f) ? static_cast<double>(od.step) : 0.0;
     return o;
 }
 

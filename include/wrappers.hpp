@@ -43,7 +43,7 @@ inline float price(const OptionData &od, uint32_t n_steps, bool window, int prec
 {
     mcamd_ctx *ctx = context();
     if (!ctx) return -1.0f;
-    const mcamd_option o = to_option(od, window);
+    const mcamd_option o = to_option(od, window, n_steps > 1);
     const mcamd_sim s = to_sim(static_cast<uint64_t>(od.N_PATHS), n_steps, 1234, precision);
     mcamd_result r;
     if (mcamd_price_paths(ctx, &o, &s, &r) != MCAMD_OK) return failed();

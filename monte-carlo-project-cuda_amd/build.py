@@ -33,6 +33,21 @@ def _flags(extra=()):
             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *extra]
 
 
+def build_id(extra=()) -> str:
+    """Hash of everything the device code is made from (kernel sources, headers, the public header, the compile
+    flags).  Compiled into the library (mcamd_build_id) and written beside the ISA slot counts
+    (profiles/valu_slots.json), so bench.py can tell whether the counts describe the kernels it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(ROOT, "include", "mcamd.h"), "rb") as f:
+        h.update(f.read())
+    h.update(" ".join(_flags(extra)[:3]).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -48,6 +63,8 @@ def _compile(src: str, force: bool, extra) -> str:
         cmd = [hipcc(), *_flags(extra), "-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):
             cmd[1:1] = ["-x", "hip", "-ffp-contract=off"]
+        if src == "capi.cpp":
+            cmd.append('-DMCAMD_BUILD_ID="' + build_id(extra) + '"')
         subprocess.check_call(cmd)
     return obj
 
@@ -58,7 +75,23 @@ def build(force: bool = False, extra_flags=(), jobs: int = 6) -> str:
         objs = list(ex.map(lambda s: _compile(s, force, tuple(extra_flags)), SOURCES))
     if force or _stale(LIB, objs):
         subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", LIB, "-ldl"])
+    refresh_slot_counts(tuple(extra_flags))
     return LIB
+
+
+def refresh_slot_counts(extra=()) -> None:
+    """Recounts the VALU issue slots of the shipped inner loops (tools/count_valu_slots.py -> profiles/valu_slots.json)
+    whenever the committed counts were taken from other sources than the library just built."""
+    import json
+    path = os.path.join(ROOT, "profiles", "valu_slots.json")
+    try:
+        with open(path) as f:
+            if json.load(f).get("build_id") == build_id(extra):
+                return
+    except (OSError, ValueError):
+        pass
+    subprocess.check_call([os.environ.get("PYTHON", "python3"), os.path.join(ROOT, "tools", "count_valu_slots.py")],
+                          stdout=subprocess.DEVNULL)
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ REDUCE_SEQUENTIAL, REDUCE_FIRST_ADD, REDUCE_UNROLL_LAST, REDUCE_GRID_STRIDE = 3,
 
 # every symbol include/mcamd.h declares
 EXPORTS = [
-    "mcamd_abi_version", "mcamd_last_error", "mcamd_device_count", "mcamd_ctx_create", "mcamd_ctx_destroy",
+    "mcamd_abi_version", "mcamd_last_error", "mcamd_build_id", "mcamd_device_count", "mcamd_ctx_create", "mcamd_ctx_destroy",
     "mcamd_get_device_info", "mcamd_device_malloc", "mcamd_device_free", "mcamd_memcpy_to_host",
     "mcamd_memcpy_to_device", "mcamd_price_paths", "mcamd_price_paths_enqueue", "mcamd_enqueued_kernel_ms",
     "mcamd_finalize_stats", "mcamd_group_create", "mcamd_group_destroy", "mcamd_group_size",
@@ -34,7 +34,7 @@ EXPORTS = [
 class Option(C.Structure):
     _fields_ = [("S0", C.c_double), ("T", C.c_double), ("K", C.c_double), ("r", C.c_double), ("v", C.c_double),
                 ("B", C.c_double), ("P1", C.c_int32), ("P2", C.c_int32), ("use_window", C.c_int32),
-                ("Ik", C.c_int32), ("Sk", C.c_double), ("Tk", C.c_int32), ("reserved", C.c_int32)]
+                ("Ik", C.c_int32), ("Sk", C.c_double), ("Tk", C.c_int32), ("reserved", C.c_int32), ("dt", C.c_double)]
 
 
 class Sim(C.Structure):
@@ -47,7 +47,8 @@ class Result(C.Structure):
     _fields_ = [("sum", C.c_double), ("sumsq", C.c_double), ("n", C.c_uint64), ("price", C.c_double),
                 ("std_err", C.c_double), ("ci_lo", C.c_double), ("ci_hi", C.c_double), ("kernel_ms", C.c_float),
                 ("total_ms", C.c_float), ("grid", C.c_uint32), ("block", C.c_uint32), ("sum_c", C.c_double),
-                ("sum_cc", C.c_double), ("sum_yc", C.c_double), ("cv_beta", C.c_double), ("cv_rho", C.c_double)]
+                ("sum_cc", C.c_double), ("sum_yc", C.c_double), ("cv_beta", C.c_double), ("cv_rho", C.c_double),
+                ("work_steps", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -83,6 +84,7 @@ def load() -> C.CDLL:
     vp, u64, i32, f32, f64 = C.c_void_p, C.c_uint64, C.c_int, C.c_float, C.c_double
     L.mcamd_abi_version.restype = i32
     L.mcamd_last_error.restype = C.c_char_p
+    L.mcamd_build_id.restype = C.c_char_p
     L.mcamd_device_count.argtypes = [C.POINTER(i32)]
     L.mcamd_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
     L.mcamd_ctx_destroy.argtypes = [vp]
@@ -128,8 +130,8 @@ def _check(rc: int):
 
 
 def make_option(S0=100.0, T=1.0, K=100.0, r=0.1, v=0.2, B=0.0, P1=0, P2=0, use_window=0, Ik=0, Sk=0.0,
-                Tk=0) -> Option:
-    return Option(S0, T, K, r, v, B, P1, P2, use_window, Ik, Sk, Tk, 0)
+                Tk=0, dt=0.0) -> Option:
+    return Option(S0, T, K, r, v, B, P1, P2, use_window, Ik, Sk, Tk, 0, dt)
 
 
 def make_sim(n_paths, n_steps=1, precision=F64, seed=1234, path_offset=0, n_paths_local=None,
@@ -177,6 +179,10 @@ def bs_call_f32(S0, K, T, r, sigma):
 
 def bs_call_f64(S0, K, T, r, sigma):
     return float(load().mcamd_bs_call_f64(S0, K, T, r, sigma))
+
+
+def build_id() -> str:
+    return load().mcamd_build_id().decode()
 
 
 def device_count() -> int:

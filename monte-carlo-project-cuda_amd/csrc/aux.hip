@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
     for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * kWaves + wave; t < n_tiles; t += wave_stride) {
         const uint64_t path0 = t * kWave;
         const uint64_t my_path = path0 + lane;
-        T St = c.S_start;
+        PathState<T> ps = PathState<T>::start(c.S_start);
         int32_t count = c.Ik;
         // VEC: the next tile's global loads are issued into registers before the current tile is consumed, so a
         // wave always has loads in flight underneath its own (serially dependent) step loop
@@ -97,14 +97,14 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
 #pragma unroll
                         for (int k = 0; k < V; ++k)
                             if (static_cast<uint32_t>(i * V + k) < n_cols) {
-                                St = gbm_step(St, zz[i][k], c, m);
-                                if (WINDOW) count += (c.B > St) ? 1 : 0;
+                                ps.step(__builtin_fma(zz[i][k], c.vol, c.drift), m);
+                                if (WINDOW) count += (c.B > ps.value(m)) ? 1 : 0;
                             }
                 }
             } else if (my_path < a.n_local) {
                 for (uint32_t j = 0; j < n_cols; ++j) {
-                    St = gbm_step(St, tile[wave][lane][j], c, m);
-                    if (WINDOW) count += (c.B > St) ? 1 : 0;
+                    ps.step(__builtin_fma(tile[wave][lane][j], c.vol, c.drift), m);
+                    if (WINDOW) count += (c.B > ps.value(m)) ? 1 : 0;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (my_path < a.n_local) {
-            const T pay = payoff<T, WINDOW>(St, count, c);
+            const T pay = payoff<T, WINDOW>(ps.value(m), count, c);
             if (a.payoffs) a.payoffs[my_path] = pay;
             const double pd = static_cast<double>(pay);
             s += pd;
@@ -319,6 +319,9 @@ hipError_t launch_final_reduce(const double *d_partials, uint32_t n_records, int
 {
     if (record_doubles == 5)
         hipLaunchKernelGGL(final_reduce_kernel<5>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out,
+                           n_value);
+    else if (record_doubles == 3)
+        hipLaunchKernelGGL(final_reduce_kernel<3>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out,
                            n_value);
     else
         hipLaunchKernelGGL(final_reduce_kernel<2>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out,

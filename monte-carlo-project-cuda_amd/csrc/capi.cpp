@@ -12,7 +12,7 @@
 #include <cstring>
 #include <string>
 
-static_assert(sizeof(mcamd_option) == 80 && sizeof(mcamd_sim) == 48 && sizeof(mcamd_result) == 112 &&
+static_assert(sizeof(mcamd_option) == 88 && sizeof(mcamd_sim) == 48 && sizeof(mcamd_result) == 120 &&
                   sizeof(mcamd_device_info) == 384,
               "C ABI struct layout changed: bump MCAMD_ABI_VERSION");
 
@@ -91,17 +91,30 @@ int check_common(const mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim 
     if (!(opt->T > 0.0) || !(opt->v >= 0.0) || !std::isfinite(opt->S0) || !std::isfinite(opt->K) ||
         !std::isfinite(opt->r) || !std::isfinite(opt->T) || !std::isfinite(opt->v))
         return fail(MCAMD_ERR_INVALID, "option parameters must be finite with T > 0 and v >= 0");
+    if (!(opt->dt >= 0.0) || !std::isfinite(opt->dt))
+        return fail(MCAMD_ERR_INVALID, "dt must be 0 (= T / n_steps) or a positive finite step, got %g", opt->dt);
     if (sim->flags & ~(MCAMD_FLAG_LOG_SPACE | MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
         return fail(MCAMD_ERR_INVALID, "unknown bits in flags: %d", sim->flags);
     if (sim->path_offset + sim->n_paths_local < sim->path_offset)
         return fail(MCAMD_ERR_INVALID, "path_offset + n_paths_local overflows 64 bits");
+    if (sim->precision == MCAMD_F64) {
+        // fp64 keeps a path's exponent as an int32 count of 2^-16 octaves (fast64.hpp ExpAcc): bound the largest
+        // log-return a path can reach (|z| <= 8.6 for the 53-bit Box-Muller uniform).  A job beyond this has prices
+        // outside the range of a double anyway (e^709); the fp32 path saturates in hardware.
+        const double dt = opt->dt > 0.0 ? opt->dt : opt->T / static_cast<double>(sim->n_steps);
+        const double per_step = std::fabs((opt->r - 0.5 * opt->v * opt->v) * dt) + 8.6 * opt->v * std::sqrt(dt);
+        if (!(per_step < 700.0) || !(per_step * static_cast<double>(sim->n_steps) < 20000.0))
+            return fail(MCAMD_ERR_INVALID,
+                        "fp64 path: |drift| + 8.6 vol = %.3g per step over %u steps exceeds the exponent range "
+                        "(per step < 700, per path < 20000)", per_step, sim->n_steps);
+    }
     return MCAMD_OK;
 }
 
 mcamd::PathJob make_job(const mcamd_option *opt, const mcamd_sim *sim)
 {
     mcamd::PathJob j;
-    const double dt = opt->T / static_cast<double>(sim->n_steps);
+    const double dt = opt->dt > 0.0 ? opt->dt : opt->T / static_cast<double>(sim->n_steps);
     j.drift = (opt->r - 0.5 * opt->v * opt->v) * dt;
     j.vol = opt->v * std::sqrt(dt);
     j.K = opt->K;
@@ -147,6 +160,7 @@ int finish(mcamd_ctx *ctx, uint32_t records, mcamd_result *res, int record_doubl
         res->sum_cc = ctx->h_out[3];
         res->sum_yc = ctx->h_out[4];
     }
+    if (record_doubles == mcamd::kNmcRecord) res->work_steps = 64.0 * ctx->h_out[2];  // wave-steps x 64 lanes
     return MCAMD_OK;
 }
 
@@ -229,6 +243,14 @@ int mcamd_abi_version(void)
 const char *mcamd_last_error(void)
 {
     return g_last_error.c_str();
+}
+
+#ifndef MCAMD_BUILD_ID
+#define MCAMD_BUILD_ID "unknown"
+#endif
+const char *mcamd_build_id(void)
+{
+    return MCAMD_BUILD_ID;
 }
 
 int mcamd_device_count(int *count)
@@ -558,11 +580,11 @@ int mcamd_nmc_inner(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
     job.discount = std::exp(-opt->r * opt->T);
     job.n_points = n_points;
     const uint32_t grid = mcamd::nmc_grid(job, variant);
-    if (int rc = ensure_partials(ctx, grid)) return rc;
+    if (int rc = ensure_partials(ctx, grid, mcamd::kNmcRecord)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(mcamd::launch_nmc_inner(job, layout, variant, d_prices, d_counts, d_point_prices, ctx->d_partials, grid,
                                     ctx->stream));
-    if (int rc = finish(ctx, grid, res)) return rc;
+    if (int rc = finish(ctx, grid, res, mcamd::kNmcRecord)) return rc;
     res->n = n_points;
     res->price = n_points ? res->sum / static_cast<double>(n_points) : 0.0;  // mean point price (diagnostic)
     res->grid = grid;
@@ -579,6 +601,9 @@ int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
     if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
         return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
     if (opt->Tk != 0) return fail(MCAMD_ERR_INVALID, "nested MC simulates outer trajectories from step 0 (Tk = 0)");
+    if (outer_seed == sim->seed)
+        return fail(MCAMD_ERR_INVALID, "outer_seed must differ from the inner seed (sim->seed): equal seeds would make "
+                                       "outer path p and inner path p draw the same Philox stream");
     if (sim->n_paths_inner == 0) return fail(MCAMD_ERR_INVALID, "n_paths_inner must be >= 1");
     zero_result(res);
     if (sim->n_paths_local == 0) return MCAMD_OK;
@@ -593,11 +618,11 @@ int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
     job.discount = std::exp(-opt->r * opt->T);
     job.n_points = n_points;
     const uint32_t grid = mcamd::nmc_fused_grid(job);
-    if (int rc = ensure_partials(ctx, grid)) return rc;
+    if (int rc = ensure_partials(ctx, grid, mcamd::kNmcRecord)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(mcamd::launch_nmc_fused(job, outer_seed, layout, d_prices, d_counts, d_point_prices, ctx->d_partials, grid,
                                     ctx->stream));
-    if (int rc = finish(ctx, grid, res)) return rc;
+    if (int rc = finish(ctx, grid, res, mcamd::kNmcRecord)) return rc;
     res->n = n_points;
     res->price = res->sum / static_cast<double>(n_points);
     res->grid = grid;

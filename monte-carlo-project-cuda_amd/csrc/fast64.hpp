@@ -9,10 +9,13 @@
 //
 //   neg2log(u)        -2 ln u          u in [2^-53, 1]                 10 fp64 ops
 //   sqrt_pos(a)       sqrt(a)          a >= 0 (clamped to >= 1e-300)   v_rsq_f64 + 8 fp64 ops
-//   sincos_q(q)       sin, cos(pi q/256) q = 256 t, t in (0, 2]        14 fp64 ops
-//   mul_exp(S, x)     S * e^x          |x| < 700                       10 fp64 ops
+//   sincos_bits(z,w)  sin, cos(pi t)   t = (v2 + 1) 2^-52 from two Philox words: 11 fp64 ops, no int->fp convert
+//   ExpAcc            running product of e^x_i kept as 2^(k/65536) * P: 6 fp64 ops per factor, no table
+//                     lookup until the value is needed (exp_acc_value: 2 lookups, 3 multiplies, ldexp)
 // Accuracy (tests/test_fast64.py, against long-double libm on 4M random arguments each):
-// <= 2 ulp for neg2log / mul_exp, <= 1 ulp sqrt_pos, <= 2e-16 absolute for sin / cos.
+// <= 2 ulp for neg2log, <= 1 ulp sqrt_pos, <= 2.5e-16 absolute for sin / cos, <= 4.5 ulp for a single
+// exp factor S e^x (|x| <= 1) and <= 64 ulp (observed 36) for a 252-factor product, whose rounding
+// random-walks like any fp64 product recurrence of that length.
 //
 // The header compiles for the host too (plain g++), with the tables as ordinary arrays and the
 // hardware reciprocal square root emulated at reduced precision, so the numerics are unit-tested
@@ -38,9 +41,10 @@ struct alignas(16) D2 {
 
 // Pointers to the three tables: LDS copies inside a kernel, the static arrays on the host.
 struct Tables {
-    const D2 *log_tab;     // {-2/c_i, -2 ln c_i}
-    const D2 *sincos_tab;  // {sin, cos}(2 pi j / 512)
-    const double *exp_tab; // 2^(j/512)
+    const D2 *log_tab;        // {-2/c_i, -2 ln c_i}
+    const D2 *sincos_tab;     // {sin, cos}(2 pi (j + 1/2) / 512): nodes at the MIDDLE of each of the 512 arcs
+    const double *exp_hi_tab; // 2^(i/256),   i in [0, 256)
+    const double *exp_lo_tab; // 2^(i/65536), i in [0, 256)
 };
 
 MC_HD uint32_t hi32(double x)
@@ -100,11 +104,28 @@ MC_HD double fma_vvs(double a, double b, double k)
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
     return d;
 }
+//   fma_vvv(a, b, c)  a * b + c         c a loop-invariant constant kept in VGPRs
+MC_HD double fma_vvv(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 #else
 MC_HD double fma_us(double a, double k) { return __builtin_fma(a, k, k); }
 MC_HD double fma_usv(double a, double k, double c) { return __builtin_fma(a, k, c); }
 MC_HD double fma_vvs(double a, double b, double k) { return __builtin_fma(a, b, k); }
+MC_HD double fma_vvv(double a, double b, double c) { return __builtin_fma(a, b, c); }
 #endif
+// Hides a value's provenance from the optimiser (no instruction).  Used where ROCm 7.2's instruction selection
+// otherwise rewrites "(lo32(M * c) >> 11) & 0xfff" on a Philox output word into a second 32-bit multiply.
+MC_HD uint32_t opaque(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(x));
+#endif
+    return x;
+}
 
 // (v + 1) * c with v = x ^ (y << 21) the 53-bit integer rocRAND builds from two Philox words
 // (rocrand_normal.h box_muller_double).  v = hi 2^32 + lo is exact in a double (v < 2^53), and
@@ -123,7 +144,8 @@ MC_HD double u53(uint32_t x, uint32_t y, double c)
 
 // -2 ln(u) for u in [2^-53, 1].  u = 2^k z, z in [0.6875, 1.375); chunk i (top 9 bits of z's bit pattern
 // above 0.6875) selects c_i; t = -2 (z / c_i - 1) is tiny (|t| < 2^-9), and
-// -2 ln(1 - t/2) = t + t^2/4 + t^3/12 + t^4/32 + t^5/80 + t^6/192 (next term < 1.2e-19 relative).
+// -2 ln(1 - t/2) = t + t^2/4 + t^3/12 + t^4/32 + t^5/80 (the dropped t^6/192 is < 2.9e-19 absolute, i.e. below
+// 0.7 ulp of the result even in the one chunk, next to u = 1, where the table term is zero).
 MC_HD double neg2log(double u, const D2 *tab)
 {
     const uint32_t hx = hi32(u);
@@ -134,10 +156,9 @@ MC_HD double neg2log(double u, const D2 *tab)
     const D2 e = tab[i];
     const double t = __builtin_fma(z, e.a, 2.0);
     const double w = __builtin_fma(static_cast<double>(k), kM2Ln2, e.b);
-    double q = fma_usv(t, 1.0 / 192.0, 1.0 / 80.0);
-    q = __builtin_fma(t, q, 1.0 / 32.0);
-    q = __builtin_fma(t, q, 1.0 / 12.0);
-    q = __builtin_fma(t, q, 0.25);
+    double q = fma_usv(t, 1.0 / 80.0, 1.0 / 32.0);
+    q = fma_vvv(t, q, 1.0 / 12.0);
+    q = fma_vvv(t, q, 0.25);
     return w + __builtin_fma(t * t, q, t);
 }
 
@@ -155,43 +176,110 @@ MC_HD double sqrt_pos(double a)
     return __builtin_fma(d, h, g);
 }
 
-// sin and cos of pi * t given q = 256 t (exact), t in (0, 2]: angle = (2 pi / 512)(j + f),
-// j = rint(q), f = q - j in [-1/2, 1/2]; the table gives sin/cos of the node, and for |d| <= pi/512
-// sin d = d + d^3 (-1/6 + d^2/120), cos d = 1 + d^2 (-1/2 + d^2/24) are exact to < 1e-16.
-MC_HD void sincos_q(double q, const D2 *tab, double &s, double &c)
+// k * sqrt(a), a >= 0, for the Box-Muller radius times the step volatility: hardware reciprocal-sqrt seed y
+// (relative error e0 <= 2^-22), e = 1 - a y^2, sqrt(a) = a y (1 - e)^(-1/2) = a y (1 + e/2 + 3 e^2/8 + O(e^3)):
+// one cubic step, six fp64 operations including the scaling (sqrt_pos + multiply: eight); <= 1.5 ulp.
+MC_HD double sqrt_scaled(double a, double k)
 {
-    const double j = __builtin_rint(q);
-    const double f = q - j;
-    const int32_t ji = static_cast<int32_t>(j);
-    const D2 e = tab[ji & 511];
-    const double d = f * kTwoPiOverN;
-    const double z = d * d;
-    const double sp = fma_usv(z, 1.0 / 120.0, -1.0 / 6.0);
-    const double sd = __builtin_fma(d * z, sp, d);
-    const double cp = __builtin_fma(z, 1.0 / 24.0, -0.5);
-    const double cd = __builtin_fma(z, cp, 1.0);
+    a = __builtin_fmax(a, 1e-300);
+    const double y = rsq_seed(a);
+    const double g = a * y;
+    const double e = __builtin_fma(-y, g, 1.0);
+    const double t = e * fma_usv(e, 0.375, 0.5);
+    const double gk = g * k;
+    return __builtin_fma(gk, t, gk);
+}
+
+// sin and cos of the Box-Muller angle pi * t, t = (v2 + 1) 2^-52 in (0, 2], straight from the two Philox words
+// (z, w) rocRAND builds v2 from (v2 = z ^ (w << 21) in the low word, w >> 11 above it: 53 bits).
+//   pi t = (2 pi / 512)(j + 1/2 + f),   j = v2 >> 44 (the top 9 bits of w),
+//   f = ((v2 mod 2^44) + 1) 2^-44 - 1/2  in (-1/2, 1/2].
+// f needs no integer-to-double conversion: the 44 low bits of v2 are dropped into the mantissa of 2^52
+// (D = 2^52 + (v2 mod 2^44), one and-or on the high word) and f = fma(D, 2^-44, 2^-44 - 256.5) is exact.
+// The table holds sin/cos at the arc MIDPOINTS, so the offset d = f (2 pi / 512) has |d| <= pi/512 and
+// sin d = d - d^3/6 + d^5/120, cos d = 1 - d^2/2 + d^4/24 are exact to < 1e-16; the powers of 2 pi / 512 are
+// folded into the coefficients (kSinF1.., kCosF2..), so the polynomials run on f itself.
+MC_HD void sincos_bits(uint32_t z, uint32_t w, const D2 *tab, double &s, double &c)
+{
+    w = opaque(w);
+    const uint32_t lo = z ^ (w << 21);
+    const uint32_t hi = ((w >> 11) & 0xfffu) | 0x43300000u;
+    const double f = fma_usv(make_double(lo, hi), 0x1p-44, 0x1p-44 - 256.5);
+    const D2 e = *reinterpret_cast<const D2 *>(reinterpret_cast<const char *>(tab) + ((w >> 19) & 0x1ff0u));
+    const double ff = f * f;
+    double sp = fma_usv(ff, kSinF5, kSinF3);
+    sp = fma_vvs(ff, sp, kSinF1);
+    const double sd = f * sp;
+    const double cp = fma_usv(ff, kCosF4, kCosF2);
+    const double cd = __builtin_fma(ff, cp, 1.0);
     s = __builtin_fma(e.a, cd, e.b * sd);
     c = __builtin_fma(e.b, cd, -(e.a * sd));
 }
 
-// S * exp(x): x = (k / 512) ln 2 + r, |r| <= ln2 / 1024; 2^(k/512) = 2^(k >> 9) * table[k & 511];
-// e^r = 1 + r + r^2 (1/2 + r/6 + r^2/24) (next term r^5/120 < 1.3e-18).
-MC_HD double mul_exp(double S, double x, const double *tab)
+// ---------------------------------------------------------------------------------------------
+// Running product of exponentials, S * e^(x_1) * e^(x_2) * ... — the GBM recurrence St *= exp(x)
+// (inc/trajectories.cuh:146) — kept in factored form 2^(k / 65536) * P:
+//   each factor:  y = x * 65536 / ln 2 (the caller folds that scale into its drift and volatility constants);
+//                 n = rint(y), rr = y - n exact, |rr| <= 1/2;  e^x = 2^(n/65536) * e^(rr ln2/65536);
+//                 k += n (integer, exact);  P *= 1 + rr (c1 + c2 rr)   with c1 = ln2/65536, c2 = c1^2/2
+//                 (|r| = |rr c1| <= 5.3e-6, so the dropped r^3/6 is < 2.5e-17: a quarter ulp);
+//   the value:    ldexp(((S * 2^(hi/256)) * 2^(lo/65536)) * P, k >> 16),  hi = bits 15..8 of k, lo = bits 7..0.
+// The power-of-two part of every factor is accumulated exactly, in an integer, so a path that only needs its
+// terminal price (European payoff) does six fp64 operations per step and looks nothing up until the end; a
+// path that needs St at every step (barrier count, trajectory store) evaluates the value each step — the
+// same expression, so the last stored price and the in-register terminal price are the same bits.
+// Range: |k| < 2^31 over the whole path (the host checks n_steps * max|y|, capi.cpp); ldexp saturates to
+// inf / 0 like exp does.
+// ---------------------------------------------------------------------------------------------
+constexpr int kExpBits = 16;
+
+struct ExpAcc {
+    double P;
+    int32_t k;
+};
+
+MC_HD ExpAcc exp_acc_init() { return ExpAcc{1.0, 0}; }
+
+// multiplies the running product by e^x, given y = x * kExpScale.  c1 = kExpC1, passed in so that a kernel
+// can keep it in vector registers across its step loop (exp_c1_resident).
+MC_HD void exp_acc_mul(ExpAcc &a, double y, double c1 = kExpC1)
 {
-    // round-to-nearest by adding 1.5 * 2^52: the integer lands in the low mantissa word (|x| < 2^20)
-    const double ks = __builtin_fma(x, kNOverLn2, 0x1.8p52);
-    const int32_t ki = static_cast<int32_t>(lo32(ks));
+    // round-to-nearest by adding 1.5 * 2^52: the integer lands in the low mantissa word (|y| < 2^31)
+    const double ks = y + 0x1.8p52;
     const double kd = ks - 0x1.8p52;
-    double r = __builtin_fma(kd, -kLn2OverN_hi, x);
-    r = __builtin_fma(kd, -kLn2OverN_lo, r);
-    const double tv = tab[ki & 511];
-    const uint32_t bump = (static_cast<uint32_t>(ki) & 0xfffffe00u) << 11;  // (k >> 9) << 20
-    const double sc = make_double(lo32(tv), hi32(tv) + bump);
-    double p = fma_usv(r, 1.0 / 24.0, 1.0 / 6.0);
-    p = __builtin_fma(r, p, 0.5);
-    const double tmp = __builtin_fma(r * r, p, r);
-    const double Ss = S * sc;
-    return __builtin_fma(Ss, tmp, Ss);
+    const double rr = y - kd;
+    a.k += static_cast<int32_t>(lo32(ks));
+    const double t = rr * fma_usv(rr, kExpC2, c1);
+    a.P = __builtin_fma(a.P, t, a.P);
+}
+
+// kExpC1 in vector registers, opaque to rematerialisation: without this hipcc (ROCm 7.2) re-creates the constant
+// from scalar registers in front of every use inside the step loop (one v_mov_b64 per iteration).
+MC_HD double exp_c1_resident()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double c;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(c) : "s"(kExpC1));
+    return c;
+#else
+    return kExpC1;
+#endif
+}
+
+MC_HD double exp_acc_value(double S, const ExpAcc &a, const double *hi_tab, const double *lo_tab)
+{
+    const uint32_t k = static_cast<uint32_t>(a.k);
+    const double th = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(hi_tab) + ((k >> 5) & 0x7f8u));
+    const double tl = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lo_tab) + ((k << 3) & 0x7f8u));
+    return __builtin_ldexp(((S * th) * tl) * a.P, a.k >> kExpBits);
+}
+
+// S * e^x for one natural-units exponent (the log-space mode's single exponentiation, tests)
+MC_HD double mul_exp(double S, double x, const double *hi_tab, const double *lo_tab)
+{
+    ExpAcc a = exp_acc_init();
+    exp_acc_mul(a, x * kExpScale);
+    return exp_acc_value(S, a, hi_tab, lo_tab);
 }
 
 }  // namespace f64

@@ -38,7 +38,7 @@ uint32_t array_grid(uint64_t n_local);
 hipError_t launch_from_normals(const PathJob &job, const void *d_normals, void *d_payoffs, double *d_partials,
                                uint32_t grid, hipStream_t stream);
 
-// sums n_records records of record_doubles (2 or 5) doubles into d_out[0..record_doubles)
+// sums n_records records of record_doubles (2, 3 or 5) doubles into d_out[0..record_doubles)
 // n_value >= 0: also zero-fill d_out[record_doubles..5) and write d_out[5] = n_value (the 6-double stats layout)
 hipError_t launch_final_reduce(const double *d_partials, uint32_t n_records, int record_doubles, double *d_out,
                                hipStream_t stream, double n_value = -1.0);
@@ -55,6 +55,8 @@ struct NmcJob {
     double discount;         // exp(-r T)
     uint64_t n_points;       // n_local * n_steps
 };
+// the nested-MC kernels write 3-double block records: {sum of point prices, sum of squares, wave-steps executed}
+constexpr int kNmcRecord = 3;
 uint32_t nmc_grid(const NmcJob &job, int variant);
 hipError_t launch_nmc_inner(const NmcJob &job, int layout, int variant, const void *d_prices, const int32_t *d_counts,
                             void *d_point_prices, double *d_partials, uint32_t grid, hipStream_t stream);

@@ -68,19 +68,24 @@ struct MathCtx {
 template <>
 struct MathCtx<double> {
     f64::Tables t;
+    double exp_c1;  // f64::kExpC1, resident in vector registers for the step loops
     // Must be called by every thread of the workgroup (contains a barrier).
     __device__ __forceinline__ static MathCtx init()
     {
         __shared__ f64::D2 s_log[MCAMD_TAB_N];
         __shared__ f64::D2 s_sincos[MCAMD_TAB_N];
-        __shared__ double s_exp[MCAMD_TAB_N];
+        __shared__ double s_exp_hi[256];
+        __shared__ double s_exp_lo[256];
         for (int i = threadIdx.x; i < MCAMD_TAB_N; i += blockDim.x) {
             s_log[i] = f64::D2{kLogTab[i][0], kLogTab[i][1]};
             s_sincos[i] = f64::D2{kSinCosTab[i][0], kSinCosTab[i][1]};
-            s_exp[i] = kExp2Tab[i];
+        }
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+            s_exp_hi[i] = kExpHiTab[i];
+            s_exp_lo[i] = kExpLoTab[i];
         }
         __syncthreads();
-        return MathCtx{f64::Tables{s_log, s_sincos, s_exp}};
+        return MathCtx{f64::Tables{s_log, s_sincos, s_exp_hi, s_exp_lo}, f64::exp_c1_resident()};
     }
 };
 
@@ -88,7 +93,7 @@ struct MathCtx<double> {
 // Box-Muller, rocRAND convention (rocrand_normal.h box_muller / box_muller_double):
 //   fp32: u = 2^-32 + x 2^-32, angle = 2 pi (2^-32 + y 2^-32), (sin, cos) * sqrt(-2 ln u)
 //   fp64: u = 2^-53 + v1 2^-53 with v1 = x ^ (y << 21); angle = pi * (2^-52 + v2 2^-52)
-// fp64 uses the table-driven functions of fast64.hpp (u and the angle are exact, the elementary
+// fp64 uses the table-driven functions of fast64.hpp (u and the angle's reduction are exact, the elementary
 // functions are within 2 ulp of libm).  fp32 uses the hardware transcendental unit directly: v_log_f32 (log2), v_sqrt_f32 and
 // v_sin_f32 / v_cos_f32, whose operand is in revolutions, so the angle needs no 2 pi multiply
 // and no range reduction.
@@ -107,10 +112,9 @@ __device__ __forceinline__ void box_muller(uint32_t x, uint32_t y, float &a, flo
 __device__ __forceinline__ void box_muller(const U4 &w, const MathCtx<double> &m, double &a, double &b)
 {
     const double u = f64::u53(w.x, w.y, 0x1p-53);   // (v1 + 1) 2^-53, exact
-    const double q = f64::u53(w.z, w.w, 0x1p-44);   // 256 (v2 + 1) 2^-52, exact
     const double s = f64::sqrt_pos(f64::neg2log(u, m.t.log_tab));
     double sn, cs;
-    f64::sincos_q(q, m.t.sincos_tab, sn, cs);
+    f64::sincos_bits(w.z, w.w, m.t.sincos_tab, sn, cs);   // angle pi (v2 + 1) 2^-52, from the bits
     a = sn * s;
     b = cs * s;
 }
@@ -144,43 +148,48 @@ struct Normals<double> {
 };
 
 // ---------------------------------------------------------------------------------------------
-// GBM step constants and the step itself:  St *= exp(drift + vol * G)
-// (inc/trajectories.cuh:146, :224, :302; one-step form :75).  For fp32 the constants are
-// pre-multiplied by log2(e) on the host so the step is v_fma_f32 + v_exp_f32 + v_mul_f32.
+// GBM step constants and the running price of a path:  St *= exp(drift + vol * G)
+// (inc/trajectories.cuh:146, :224, :302; one-step form :75).  The exponent constants are pre-scaled on the host
+// to the unit the precision's exponential consumes: log2(e) for fp32 (v_exp_f32 computes 2^x), 65536 / ln 2 for
+// fp64 (f64::ExpAcc splits the exponent at 2^-16 octaves).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 struct StepConsts {
-    T drift;    // (r - v^2/2) dt          [fp32: times log2 e]
-    T vol;      // v sqrt(dt)              [fp32: times log2 e]
+    T drift;    // (r - v^2/2) dt          [times the exponent scale]
+    T vol;      // v sqrt(dt)              [times the exponent scale]
     T vol_bm;   // fp32: vol * sqrt(2 ln 2), so that vol * sqrt(-2 ln u) = vol_bm * sqrt(-log2 u); fp64: = vol
     T K;        // strike
     T B;        // barrier
     T S_start;  // S0, or Sk when restarting
-    T logB;     // ln(B / S_start) [fp32: log2], -inf when B <= 0: barrier test in log space
+    T logB;     // ln(B / S_start) in exponent units, -inf when B <= 0: barrier test in log space
     int32_t P1, P2, Ik;
     uint32_t n_sim;  // steps to simulate = n_steps - Tk
 };
 
-__device__ __forceinline__ float gbm_step(float St, float G, const StepConsts<float> &c, const MathCtx<float> &)
-{
-    return St * __builtin_amdgcn_exp2f(__builtin_fmaf(G, c.vol, c.drift));
-}
+// Running price of one path.  fp32: the price itself, one v_exp_f32 and one multiply per step.  fp64: the start
+// price and the factored product of the step exponentials (f64::ExpAcc); value() evaluates it.
+template <typename T>
+struct PathState;
 
-__device__ __forceinline__ double gbm_step(double St, double G, const StepConsts<double> &c, const MathCtx<double> &m)
-{
-    return f64::mul_exp(St, __builtin_fma(G, c.vol, c.drift), m.t.exp_tab);
-}
+template <>
+struct PathState<float> {
+    float St;
+    __device__ __forceinline__ static PathState start(float S) { return PathState{S}; }
+    __device__ __forceinline__ void step(float x, const MathCtx<float> &) { St *= __builtin_amdgcn_exp2f(x); }
+    __device__ __forceinline__ float value(const MathCtx<float> &) const { return St; }
+};
 
-// GBM step from a ready exponent x = drift + vol G.
-__device__ __forceinline__ float gbm_step_x(float St, float x, const MathCtx<float> &)
-{
-    return St * __builtin_amdgcn_exp2f(x);
-}
-
-__device__ __forceinline__ double gbm_step_x(double St, double x, const MathCtx<double> &m)
-{
-    return f64::mul_exp(St, x, m.t.exp_tab);
-}
+template <>
+struct PathState<double> {
+    double S0;
+    f64::ExpAcc a;
+    __device__ __forceinline__ static PathState start(double S) { return PathState{S, f64::exp_acc_init()}; }
+    __device__ __forceinline__ void step(double y, const MathCtx<double> &m) { f64::exp_acc_mul(a, y, m.exp_c1); }
+    __device__ __forceinline__ double value(const MathCtx<double> &m) const
+    {
+        return f64::exp_acc_value(S0, a, m.t.exp_hi_tab, m.t.exp_lo_tab);
+    }
+};
 
 // Exponents of one Philox block: x[j] = drift + vol * z[j] for the block's normals z (4 fp32 / 2 fp64),
 // without materialising z: the Box-Muller radius is multiplied by vol once per pair and the constant
@@ -220,10 +229,9 @@ struct Exponents<double> {
     {
         const U4 w = philox_block(seed, subsequence, block);
         const double u = f64::u53(w.x, w.y, 0x1p-53);
-        const double q = f64::u53(w.z, w.w, 0x1p-44);
-        const double sv = f64::sqrt_pos(f64::neg2log(u, m.t.log_tab)) * c.vol_bm;
+        const double sv = f64::sqrt_scaled(f64::neg2log(u, m.t.log_tab), c.vol_bm);
         double sn, cs;
-        f64::sincos_q(q, m.t.sincos_tab, sn, cs);
+        f64::sincos_bits(w.z, w.w, m.t.sincos_tab, sn, cs);
         x[0] = f64::fma_vvs(sn, sv, c.drift);
         x[1] = f64::fma_vvs(cs, sv, c.drift);
     }
@@ -243,9 +251,11 @@ __device__ __forceinline__ float exp_of_logreturn(float S, float x, const MathCt
     return S * __builtin_amdgcn_exp2f(x);  // fp32 exponent constants carry log2(e)
 }
 
-__device__ __forceinline__ double exp_of_logreturn(double S, double x, const MathCtx<double> &m)
+__device__ __forceinline__ double exp_of_logreturn(double S, double y, const MathCtx<double> &m)
 {
-    return f64::mul_exp(S, x, m.t.exp_tab);
+    PathState<double> ps = PathState<double>::start(S);   // fp64 exponent constants carry 65536 / ln 2
+    ps.step(y, m);
+    return ps.value(m);
 }
 
 // Simulates n_sim steps of one path in registers from (St, count) on the Philox stream
@@ -258,20 +268,36 @@ __device__ __forceinline__ double exp_of_logreturn(double S, double x, const Mat
 // the end; the barrier test B > St becomes ln(B / S_start) > ln(St / S_start).  Same mathematics,
 // different rounding (~1e-14 relative in fp64); one add (or add + fma + compare) per step instead
 // of an exp.
+// WINDOW: the barrier count only grows, so once it is beyond P2 the payoff is 0 whatever follows
+// (inc/trajectories.cuh:149); when that holds for every lane of the wavefront, the wavefront leaves the step
+// loop (checked once per Philox block: one compare and a scalar branch).  The reference tests this only before
+// the loop (inc/nmc.cuh:53, :330); the result is the same, the work is not: with the benchmark's bullet window
+// (B = 120, P2 = 50 of 252 steps, hello.cu:11-13) a continuation path is over after ~50 steps.
 // log_start: ln(St / c.S_start) in the exponent's units (0 when the path starts at c.S_start); only read
 // in LOGSPACE + WINDOW mode, where the barrier level is held as ln(B / c.S_start).
 __device__ __forceinline__ float log_ratio(float a, float b) { return __builtin_amdgcn_logf(a / b); }  // log2
-__device__ __forceinline__ double log_ratio(double a, double b) { return log(a / b); }
+__device__ __forceinline__ double log_ratio(double a, double b) { return log(a / b) * f64::kExpScale; }
 
 // What one sample contributes: its undiscounted payoff and the control variable S_T.  With ANTI the
 // sample is the antithetic pair (G, -G) of the same normals: both members are averaged.
 template <typename T>
 struct Sample {
     T pay;   // payoff (mean of the pair with ANTI)
-    T ctrl;  // terminal price S_T (mean of the pair with ANTI)
+    T ctrl;  // terminal price S_T (mean of the pair with ANTI); with WINDOW, the price where the loop stopped
+    uint32_t steps_run;  // steps the wavefront executed (wave-uniform): n_sim unless the window let it stop early
 };
 
-template <typename T, bool WINDOW, bool LOGSPACE, bool ANTI>
+// true when no lane of the wavefront can still be paid: every barrier count is beyond P2
+template <bool ANTI>
+__device__ __forceinline__ bool window_closed(int32_t count, int32_t count2, int32_t P2)
+{
+    const bool open = ANTI ? (count <= P2 || count2 <= P2) : (count <= P2);
+    return __builtin_amdgcn_ballot_w64(open) == 0;
+}
+
+// EARLY: leave the loop when the window has closed for the whole wavefront (off when the caller needs the
+// terminal price itself, i.e. for the S_T control variate).
+template <typename T, bool WINDOW, bool LOGSPACE, bool ANTI, bool EARLY = WINDOW>
 __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, const MathCtx<T> &m, uint64_t seed,
                                                      uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
                                                      T log_start = T(0))
@@ -281,6 +307,8 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
     const uint32_t rem = n_sim - n_full * NB;
     T St2 = St;               // antithetic twin
     int32_t count2 = count;
+    uint32_t steps_run = n_sim;
+    bool rem_live = true;
     // LOGSPACE: WINDOW ? ln(St/S_start) so far : sum of the normals so far (the twin's sum is its negative)
     T acc = WINDOW ? log_start : T(0), acc2 = acc;
     if (LOGSPACE) {
@@ -301,36 +329,50 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
             nrm.fill(m, seed, subsequence, k);
 #pragma unroll
             for (int j = 0; j < NB; ++j) step(nrm.z[j]);
+            if (WINDOW && EARLY && window_closed<ANTI>(count, count2, c.P2)) {
+                steps_run = (k + 1) * NB;
+                rem_live = false;
+                break;
+            }
         }
-        if (rem) {
+        if (rem && rem_live) {
             nrm.fill(m, seed, subsequence, n_full);
 #pragma unroll
             for (int j = 0; j < NB - 1; ++j)
                 if (static_cast<uint32_t>(j) < rem) step(nrm.z[j]);
         }
     } else {
-        // the reference's recurrence: St *= exp(drift + vol G); the twin uses drift - vol G = 2 drift - x
+        // the reference's recurrence: St *= exp(drift + vol G); the twin uses drift - vol G = 2 drift - x.
+        // The barrier count needs St at every step (value()); a European path only at the end.
         Exponents<T> ex;
         const T two_drift = c.drift + c.drift;
+        PathState<T> ps = PathState<T>::start(St), ps2 = ps;
         auto step = [&](T x) {
-            St = gbm_step_x(St, x, m);
-            if (WINDOW) count += (c.B > St) ? 1 : 0;
+            ps.step(x, m);
+            if (WINDOW) count += (c.B > ps.value(m)) ? 1 : 0;
             if (ANTI) {
-                St2 = gbm_step_x(St2, two_drift - x, m);
-                if (WINDOW) count2 += (c.B > St2) ? 1 : 0;
+                ps2.step(two_drift - x, m);
+                if (WINDOW) count2 += (c.B > ps2.value(m)) ? 1 : 0;
             }
         };
         for (uint32_t k = 0; k < n_full; ++k) {
             ex.fill(m, c, seed, subsequence, k);
 #pragma unroll
             for (int j = 0; j < NB; ++j) step(ex.x[j]);
+            if (WINDOW && EARLY && window_closed<ANTI>(count, count2, c.P2)) {
+                steps_run = (k + 1) * NB;
+                rem_live = false;
+                break;
+            }
         }
-        if (rem) {
+        if (rem && rem_live) {
             ex.fill(m, c, seed, subsequence, n_full);
 #pragma unroll
             for (int j = 0; j < NB - 1; ++j)
                 if (static_cast<uint32_t>(j) < rem) step(ex.x[j]);
         }
+        St = ps.value(m);
+        if (ANTI) St2 = ps2.value(m);
     }
     if (LOGSPACE) {
         const T nd = c.drift * static_cast<T>(n_sim);
@@ -344,6 +386,7 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
         }
     }
     Sample<T> out;
+    out.steps_run = steps_run;
     out.pay = payoff<T, WINDOW>(St, count, c);
     out.ctrl = St;
     if (ANTI) {
@@ -356,9 +399,11 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
 template <typename T, bool WINDOW, bool LOGSPACE>
 __device__ __forceinline__ T simulate_path(const StepConsts<T> &c, const MathCtx<T> &m, uint64_t seed,
                                            uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
-                                           T log_start = T(0))
+                                           T log_start = T(0), uint32_t *steps_run = nullptr)
 {
-    return simulate_sample<T, WINDOW, LOGSPACE, false>(c, m, seed, subsequence, St, count, n_sim, log_start).pay;
+    const Sample<T> s = simulate_sample<T, WINDOW, LOGSPACE, false>(c, m, seed, subsequence, St, count, n_sim, log_start);
+    if (steps_run) *steps_run += s.steps_run;
+    return s.pay;
 }
 
 // ---------------------------------------------------------------------------------------------

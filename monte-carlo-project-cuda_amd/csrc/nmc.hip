@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const uint64_t wave_stride = static_cast<uint64_t>(gridDim.x) * kWaves;
-    double psum = 0.0, psumsq = 0.0;
+    double rec[kNmcRecord] = {0.0, 0.0, 0.0};  // sum of point prices, sum of squares, wave-steps executed (lane 0)
     for (uint64_t task = static_cast<uint64_t>(blockIdx.x) * kWaves + wave; task < a.n_points; task += wave_stride) {
         uint32_t step;
         uint64_t path;
@@ -66,24 +66,26 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
         const uint32_t remaining = a.n_steps - (step + 1);
         const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
         double acc = 0.0;
+        uint32_t steps_run = 0;
         if (!WINDOW || cnt0 <= a.c.P2) {
             const T ls = (WINDOW && LOGSPACE) ? log_ratio(St0, a.c.S_start) : T(0);
             for (uint32_t j = lane; j < a.n_inner; j += kWave)
                 acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(a.c, m, a.seed, point_id * a.n_inner + j,
-                                                                               St0, cnt0, remaining, ls));
+                                                                               St0, cnt0, remaining, ls, &steps_run));
         }
         acc = wave_sum(acc);
         if (lane == 0) {
             const double price = acc * a.scale;
             a.out[idx] = static_cast<T>(price);
-            psum += price;
-            psumsq = __builtin_fma(price, price, psumsq);
+            rec[0] += price;
+            rec[1] = __builtin_fma(price, price, rec[1]);
+            rec[2] += static_cast<double>(steps_run);   // lane 0 takes part in every pass over the inner paths
         }
     }
-    block_sum2<kBlock>(psum, psumsq);
+    block_sumN<kBlock, kNmcRecord>(rec);
     if (threadIdx.x == 0) {
-        partials[2 * blockIdx.x] = psum;
-        partials[2 * blockIdx.x + 1] = psumsq;
+#pragma unroll
+        for (int i = 0; i < kNmcRecord; ++i) partials[kNmcRecord * static_cast<uint64_t>(blockIdx.x) + i] = rec[i];
     }
 }
 
@@ -91,7 +93,7 @@ template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE>
 __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double *__restrict__ partials)
 {
     const MathCtx<T> m = MathCtx<T>::init();
-    double psum = 0.0, psumsq = 0.0;
+    double psum = 0.0, psumsq = 0.0, pwork = 0.0;
     for (uint64_t task = blockIdx.x; task < a.n_points; task += gridDim.x) {
         uint32_t step;
         uint64_t path;
@@ -100,25 +102,30 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
         const int32_t cnt0 = WINDOW ? a.counts[idx] : 0;
         const uint32_t remaining = a.n_steps - (step + 1);
         const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
-        double acc = 0.0, zero = 0.0;
+        double acc = 0.0, work = 0.0;
+        uint32_t steps_run = 0;
         if (!WINDOW || cnt0 <= a.c.P2) {
             const T ls = (WINDOW && LOGSPACE) ? log_ratio(St0, a.c.S_start) : T(0);
             for (uint32_t j = threadIdx.x; j < a.n_inner; j += kBlock)
                 acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(a.c, m, a.seed, point_id * a.n_inner + j,
-                                                                               St0, cnt0, remaining, ls));
+                                                                               St0, cnt0, remaining, ls, &steps_run));
         }
-        block_sum2<kBlock>(acc, zero);
+        // wave-steps: each wavefront's first lane runs every pass that wavefront makes
+        if ((threadIdx.x & (kWave - 1)) == 0) work = static_cast<double>(steps_run);
+        block_sum2<kBlock>(acc, work);
         if (threadIdx.x == 0) {
             const double price = acc * a.scale;
             a.out[idx] = static_cast<T>(price);
             psum += price;
             psumsq = __builtin_fma(price, price, psumsq);
+            pwork += work;
         }
         __syncthreads();  // block_sum2's LDS slots are reused by the next task
     }
     if (threadIdx.x == 0) {
-        partials[2 * blockIdx.x] = psum;
-        partials[2 * blockIdx.x + 1] = psumsq;
+        partials[kNmcRecord * static_cast<uint64_t>(blockIdx.x)] = psum;
+        partials[kNmcRecord * static_cast<uint64_t>(blockIdx.x) + 1] = psumsq;
+        partials[kNmcRecord * static_cast<uint64_t>(blockIdx.x) + 2] = pwork;
     }
 }
 
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
     // ---- phase 1: outer trajectories of the owned paths (inc/nmc.cuh:144-202) ----
     for (uint64_t i = threadIdx.x; i < n_owned; i += kBlock) {
         const uint64_t path = blockIdx.x + i * gridDim.x;
-        T St = c.S_start;
+        PathState<T> ps = PathState<T>::start(c.S_start);
         int32_t cnt = c.Ik;
         Exponents<T> ex;
         for (uint32_t step = 0; step < a.n_steps; ++step) {
@@ -155,7 +162,8 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
             T x = ex.x[0];
 #pragma unroll
             for (int j = 1; j < NB; ++j) x = (step % NB == static_cast<uint32_t>(j)) ? ex.x[j] : x;
-            St = gbm_step_x(St, x, m);
+            ps.step(x, m);
+            const T St = ps.value(m);
             if (WINDOW) cnt += (c.B > St) ? 1 : 0;
             const uint64_t idx = LAYOUT == MCAMD_STEP_MAJOR ? static_cast<uint64_t>(step) * a.n_local + path
                                                             : path * a.n_steps + step;
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
     __syncthreads();  // workgroup-scope release/acquire: this workgroup reads only what it wrote
 
     // ---- phase 2: inner stage over the owned points, one wavefront per point, long tasks first ----
-    double psum = 0.0, psumsq = 0.0;
+    double rec[kNmcRecord] = {0.0, 0.0, 0.0};
     const uint64_t n_tasks = n_owned * a.n_steps;
     for (uint64_t task = wave; task < n_tasks; task += kWaves) {
         const uint32_t step = static_cast<uint32_t>(task / n_owned);
@@ -178,24 +186,26 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
         const uint32_t remaining = a.n_steps - (step + 1);
         const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
         double acc = 0.0;
+        uint32_t steps_run = 0;
         if (!WINDOW || cnt0 <= c.P2) {
             const T ls = (WINDOW && LOGSPACE) ? log_ratio(St0, c.S_start) : T(0);
             for (uint32_t j = lane; j < a.n_inner; j += kWave)
                 acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, a.seed, point_id * a.n_inner + j, St0,
-                                                                               cnt0, remaining, ls));
+                                                                               cnt0, remaining, ls, &steps_run));
         }
         acc = wave_sum(acc);
         if (lane == 0) {
             const double price = acc * a.scale;
             a.out[idx] = static_cast<T>(price);
-            psum += price;
-            psumsq = __builtin_fma(price, price, psumsq);
+            rec[0] += price;
+            rec[1] = __builtin_fma(price, price, rec[1]);
+            rec[2] += static_cast<double>(steps_run);
         }
     }
-    block_sum2<kBlock>(psum, psumsq);
+    block_sumN<kBlock, kNmcRecord>(rec);
     if (threadIdx.x == 0) {
-        partials[2 * blockIdx.x] = psum;
-        partials[2 * blockIdx.x + 1] = psumsq;
+#pragma unroll
+        for (int i = 0; i < kNmcRecord; ++i) partials[kNmcRecord * static_cast<uint64_t>(blockIdx.x) + i] = rec[i];
     }
 }
 

@@ -12,8 +12,9 @@ namespace mcamd {
 template <typename T>
 inline StepConsts<T> make_consts(const PathJob &j)
 {
-    // fp32 path: fold log2(e) into the exponent constants (the step uses v_exp_f32 = 2^x)
-    const double scale = sizeof(T) == 4 ? 1.4426950408889634 : 1.0;
+    // exponent constants in the unit the precision's exponential consumes: log2(e) for fp32 (the step uses
+    // v_exp_f32 = 2^x), 65536 / ln 2 for fp64 (f64::ExpAcc counts in 2^-16 octaves)
+    const double scale = sizeof(T) == 4 ? 1.4426950408889634 : f64::kExpScale;
     StepConsts<T> c;
     c.drift = static_cast<T>(j.drift * scale);
     c.vol = static_cast<T>(j.vol * scale);

@@ -45,8 +45,8 @@ __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *_
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = 0.0;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_local; i += stride) {
-        const Sample<T> smp = simulate_sample<T, WINDOW, LOGSPACE, ANTI>(a.c, m, a.seed, a.path_offset + i, a.c.S_start,
-                                                                         a.c.Ik, a.c.n_sim);
+        const Sample<T> smp = simulate_sample<T, WINDOW, LOGSPACE, ANTI, WINDOW && !CV>(
+            a.c, m, a.seed, a.path_offset + i, a.c.S_start, a.c.Ik, a.c.n_sim);
         const double y = static_cast<double>(smp.pay);
         acc[0] += y;
         acc[1] = __builtin_fma(y, y, acc[1]);

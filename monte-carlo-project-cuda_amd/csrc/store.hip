@@ -72,16 +72,19 @@ __global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *_
         const int n_valid =
             VEC ? V : ((a.n_local - base >= static_cast<uint64_t>(V)) ? V : static_cast<int>(a.n_local - base));
         T St[V];
+        PathState<T> ps[V];
         int32_t cnt[V];
 #pragma unroll
         for (int p = 0; p < V; ++p) {
             St[p] = c.S_start;
+            ps[p] = PathState<T>::start(c.S_start);
             cnt[p] = c.Ik;
         }
         auto advance = [&](const Exponents<T>(&nrm)[V], int j, uint32_t step) {
 #pragma unroll
             for (int p = 0; p < V; ++p) {
-                St[p] = gbm_step_x(St[p], nrm[p].x[j], m);
+                ps[p].step(nrm[p].x[j], m);
+                St[p] = ps[p].value(m);
                 if (WINDOW) cnt[p] += (c.B > St[p]) ? 1 : 0;
             }
             if (LAYOUT == MCAMD_STEP_MAJOR) {

@@ -139,6 +139,17 @@ float oracle_bs_call_f32(float x0, float K, float T, float r, float sigma)
     return (float)((double)(x0 * n1) - (double)K * exp((double)(-r * T)) * (double)n2);
 }
 
+double oracle_bs_call_f32_grid(int n)
+{
+    int side = 1;
+    while ((side + 1) * (side + 1) <= n) ++side;
+    double acc = 0.0;
+    for (int i = 0; i < side; ++i)
+        for (int j = 0; j < side; ++j)
+            acc += oracle_bs_call_f32(100.0f, 50.0f + 100.0f * i / side, 1.0f, 0.1f, 0.05f + 0.5f * j / side);
+    return acc;
+}
+
 double oracle_bs_call_f64(double x0, double K, double T, double r, double sigma)
 {
     double sqrtT = sqrt(T);
@@ -205,7 +216,7 @@ static double path_f32_ex(const oracle_params *p, uint64_t seed, uint64_t subseq
                           double *ST_out)
 {
     const float r = (float)p->r, sigma = (float)p->v, K = (float)p->K, B = (float)p->B;
-    const float dt = (float)p->T / (float)p->n_steps;
+    const float dt = p->dt > 0.0 ? (float)p->dt : (float)p->T / (float)p->n_steps;
     const float sqrdt = sqrtf(dt);
     const float drift = (r - (sigma * sigma) / 2) * dt;
     const float vol = sigma * sqrdt;
@@ -235,7 +246,7 @@ static double path_f64_ex(const oracle_params *p, uint64_t seed, uint64_t subseq
                           double *ST_out)
 {
     const double r = p->r, sigma = p->v, K = p->K, B = p->B;
-    const double dt = p->T / (double)p->n_steps;
+    const double dt = p->dt > 0.0 ? p->dt : p->T / (double)p->n_steps;
     const double sqrdt = sqrt(dt);
     const double drift = (r - (sigma * sigma) / 2) * dt;
     const double vol = sigma * sqrdt;

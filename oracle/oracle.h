@@ -43,6 +43,10 @@ typedef struct oracle_params {
     int32_t Ik;
     double Sk;
     int32_t Tk;
+    /* time step of the multi-step loops: the reference kernels read OptionData.step (inc/tool.cuh:25,
+     * inc/trajectories.cuh:131, inc/nmc.cuh:28; the CPU pricer takes it as an argument, inc/tool.cuh:133);
+     * 0 means T / n_steps, which is what hello.cu:17 stores there */
+    double dt;
 } oracle_params;
 
 /* ---- RNG: Philox4x32-10 (Random123 constants; rocRAND counter convention) ---- */
@@ -59,6 +63,9 @@ void oracle_generate_normals_f64(uint64_t seed, uint64_t n, double *out);
 float oracle_cnd_f32(float x);                                        /* :8-30  */
 float oracle_bs_call_f32(float x0, float K, float T, float r, float sigma); /* :34-43 */
 double oracle_bs_call_f64(double x0, double K, double T, double r, double sigma); /* exact, erfc */
+/* sum of oracle_bs_call_f32 over a sqrt(n) x sqrt(n) grid of strikes 50..150 and volatilities 0.05..0.55
+ * (BASELINE configs[0]'s "1M evals over a (K, sigma) grid" timing; same grid as oracle/ref_bs_driver.cpp) */
+double oracle_bs_call_f32_grid(int n);
 
 /* ---- array-driven pricer (inc/testing.cuh:75-91; kernels inc/trajectories.cuh:14-52) ---- */
 /* normals[path * n_steps + step]; writes per-path undiscounted payoffs; returns their mean. */

@@ -46,13 +46,14 @@ class Params(C.Structure):
         ("Ik", C.c_int32),
         ("Sk", C.c_double),
         ("Tk", C.c_int32),
+        ("dt", C.c_double),
     ]
 
 
 def make_params(S0=100.0, T=1.0, K=100.0, r=0.1, v=0.2, B=0.0, P1=0, P2=0, n_paths=0, n_steps=1,
-                n_paths_inner=0, seed=1234, use_window=0, Ik=0, Sk=0.0, Tk=0) -> Params:
+                n_paths_inner=0, seed=1234, use_window=0, Ik=0, Sk=0.0, Tk=0, dt=0.0) -> Params:
     return Params(S0, T, K, r, v, B, P1, P2, n_paths, n_steps, n_paths_inner, seed, use_window,
-                  Ik, Sk, Tk)
+                  Ik, Sk, Tk, dt)
 
 
 _lib = None
@@ -141,6 +142,13 @@ def bs_call_f32(S0, K, T, r, sigma) -> float:
     return float(lib().oracle_bs_call_f32(S0, K, T, r, sigma))
 
 
+def bs_call_f32_grid(n: int) -> float:
+    L = lib()
+    L.oracle_bs_call_f32_grid.argtypes = [C.c_int]
+    L.oracle_bs_call_f32_grid.restype = C.c_double
+    return float(L.oracle_bs_call_f32_grid(n))
+
+
 def bs_call_f64(S0, K, T, r, sigma) -> float:
     return float(lib().oracle_bs_call_f64(S0, K, T, r, sigma))
 
@@ -212,6 +220,9 @@ def ref_bs():
     L.ref_CND.restype = C.c_float
     L.ref_black_scholes_CPU.argtypes = [C.c_float] * 5
     L.ref_black_scholes_CPU.restype = C.c_float
+    if hasattr(L, "ref_black_scholes_grid"):
+        L.ref_black_scholes_grid.argtypes = [C.c_int]
+        L.ref_black_scholes_grid.restype = C.c_double
     return L
 
 

@@ -25,9 +25,9 @@ static double ulp_err(double got, long double want)
 int main(int argc, char **argv)
 {
     const long n = argc > 1 ? std::atol(argv[1]) : 4000000;
-    const Tables T{reinterpret_cast<const D2 *>(kLogTab), reinterpret_cast<const D2 *>(kSinCosTab), kExp2Tab};
+    const Tables T{reinterpret_cast<const D2 *>(kLogTab), reinterpret_cast<const D2 *>(kSinCosTab), kExpHiTab, kExpLoTab};
     std::mt19937_64 gen(12345);
-    double e_log = 0, e_sqrt = 0, e_sin = 0, e_cos = 0, e_exp = 0, e_u = 0;
+    double e_log = 0, e_sqrt = 0, e_sin = 0, e_cos = 0, e_exp = 0, e_u = 0, e_prod = 0, e_wide = 0, e_sqs = 0;
     const long double PI = 3.14159265358979323846264338327950288L;
     for (long i = 0; i < n; ++i) {
         const uint64_t a = gen(), b = gen();
@@ -47,12 +47,19 @@ int main(int argc, char **argv)
         else { const double e = ulp_err(aa, want_a); if (e > e_log) e_log = e; }
         const double s = sqrt_pos(std::fmax(aa, 0.0));
         if (aa > 0) { const double e = ulp_err(s, sqrtl(static_cast<long double>(aa))); if (e > e_sqrt) e_sqrt = e; }
-        const double q = u53(z, w, 0x1p-44);
-        const uint64_t v2 = static_cast<uint64_t>(z) ^ (static_cast<uint64_t>(w) << 21);
-        const double t_ref = std::fma(static_cast<double>(v2), 0x1p-52, 0x1p-52);
-        if (q != 256.0 * t_ref) e_u = 2;
+        if (aa > 0) {
+            const double kk = 0.0126 * (1.0 + static_cast<double>(z & 1023u));   // a step volatility, any binade
+            const double e = ulp_err(sqrt_scaled(aa, kk), static_cast<long double>(kk) * sqrtl(static_cast<long double>(aa)));
+            if (e > e_sqs) e_sqs = e;
+        }
+        uint32_t zz = z, ww = w;
+        if (i % 13 == 0) { zz = 0xffffffffu; ww |= 0x7fffffu; }   // top of an arc: f = +1/2
+        if (i % 17 == 0) { zz = 0; ww &= ~0x7fffffu; }            // bottom of an arc
+        if (i == 3) { zz = 0xffffffffu; ww = 0xffffffffu; }       // t == 2 exactly
+        const uint64_t v2 = static_cast<uint64_t>(zz) ^ (static_cast<uint64_t>(ww) << 21);
+        const double t_ref = std::fma(static_cast<double>(v2), 0x1p-52, 0x1p-52);   // rocRAND's angle uniform
         double sn, cs;
-        sincos_q(q, T.sincos_tab, sn, cs);
+        sincos_bits(zz, ww, T.sincos_tab, sn, cs);
         const long double ang = PI * static_cast<long double>(t_ref);
         const double es = std::fabs(static_cast<double>(static_cast<long double>(sn) - sinl(ang)));
         const double ec = std::fabs(static_cast<double>(static_cast<long double>(cs) - cosl(ang)));
@@ -62,11 +69,34 @@ int main(int argc, char **argv)
         const double xx = (i & 1) ? (static_cast<double>(static_cast<int64_t>(a)) * 0x1p-63) * 0.2
                                   : (static_cast<double>(static_cast<int64_t>(b)) * 0x1p-63) * 300.0;
         const double S = 37.0 + static_cast<double>(z) * 0x1p-32 * 200.0;
-        const double got = mul_exp(S, xx, T.exp_tab);
+        const double got = mul_exp(S, xx, T.exp_hi_tab, T.exp_lo_tab);
         const double e = ulp_err(got, static_cast<long double>(S) * expl(static_cast<long double>(xx)));
-        if (e > e_exp) e_exp = e;
+        if (std::fabs(xx) <= 1.0) { if (e > e_exp) e_exp = e; }
+        else if (e / std::fabs(xx) > e_wide) e_wide = e / std::fabs(xx);   // the exponent's own rounding scales with |x|
+        // a 252-factor running product, the GBM recurrence: exponents of the benchmark's size, sum kept in long double
+        if (i % 64 == 0) {
+            ExpAcc acc = exp_acc_init();
+            long double sum = 0.0L;
+            std::mt19937_64 g2(a);
+            for (int k = 0; k < 252; ++k) {
+                const double xk = (static_cast<double>(static_cast<int64_t>(g2())) * 0x1p-63) * 0.06 + 1.5e-4;
+                const double yk = xk * kExpScale;
+                exp_acc_mul(acc, yk);
+                sum += static_cast<long double>(yk);   // the product is exact in y: compare in the same units
+            }
+            const double gotp = exp_acc_value(S, acc, T.exp_hi_tab, T.exp_lo_tab);
+            const long double wantp = static_cast<long double>(S) *
+                                      expl(sum * (0.693147180559945309417232121458176568L / 65536.0L));
+            const double ep = ulp_err(gotp, wantp);
+            if (ep > e_prod) e_prod = ep;
+        }
+    }
+    // saturation instead of wrap-around: a huge exponent gives inf / 0, never a finite wrong value
+    {
+        const double big = mul_exp(1.0, 800.0, T.exp_hi_tab, T.exp_lo_tab), tiny = mul_exp(1.0, -800.0, T.exp_hi_tab, T.exp_lo_tab);
+        if (!std::isinf(big) || tiny != 0.0) e_exp = 1e30;
     }
     std::printf("{\"n\": %ld, \"uniform_mismatch\": %g, \"neg2log_ulp\": %.3f, \"sqrt_ulp\": %.3f, \"sin_abs\": %.3g, "
-                "\"cos_abs\": %.3g, \"mul_exp_ulp\": %.3f}\n", n, e_u, e_log, e_sqrt, e_sin, e_cos, e_exp);
+                "\"cos_abs\": %.3g, \"mul_exp_ulp\": %.3f, \"product252_ulp\": %.3f, \"mul_exp_wide_ulp_per_unit_x\": %.3f, \"sqrt_scaled_ulp\": %.3f}\n", n, e_u, e_log, e_sqrt, e_sin, e_cos, e_exp, e_prod, e_wide, e_sqs);
     return 0;
 }

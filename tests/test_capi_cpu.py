@@ -29,12 +29,12 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mcamd_abi_version() == 2
+    assert lib.mcamd_abi_version() == 3
 
 
 def test_struct_layout_is_the_documented_abi():
-    assert C.sizeof(capi.Option) == 80 and C.sizeof(capi.Sim) == 48
-    assert C.sizeof(capi.Result) == 112 and C.sizeof(capi.DeviceInfo) == 384
+    assert C.sizeof(capi.Option) == 88 and C.sizeof(capi.Sim) == 48
+    assert C.sizeof(capi.Result) == 120 and C.sizeof(capi.DeviceInfo) == 384
 
 
 def test_closed_form_matches_reference_golden_bitwise(lib, golden):

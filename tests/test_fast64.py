@@ -16,8 +16,11 @@ def test_fast64_accuracy_against_long_double_libm(tmp_path):
     assert r["uniform_mismatch"] == 0          # u and the angle are bit-identical to rocRAND's construction
     assert r["neg2log_ulp"] <= 2.0
     assert r["sqrt_ulp"] <= 1.0
+    assert r["sqrt_scaled_ulp"] <= 2.0                   # k sqrt(a) in six operations (one cubic step)
     assert r["sin_abs"] <= 2.5e-16 and r["cos_abs"] <= 2.5e-16
-    assert r["mul_exp_ulp"] <= 2.5
+    assert r["mul_exp_ulp"] <= 4.5                       # one factor S e^x, |x| <= 1: 2 table entries + 3 multiplies
+    assert r["mul_exp_wide_ulp_per_unit_x"] <= 3.5       # |x| up to 300: the error grows with the exponent's own ulp
+    assert r["product252_ulp"] <= 64.0                   # 252-factor recurrence: rounding random-walks as sqrt(n)
 
 
 def test_tables_are_reproducible_from_the_generator():

@@ -37,9 +37,16 @@ def ctx():
     if not os.path.exists(capi.LIB_PATH):   # a box that received sources only: build the HIP library first
         pkg.build()
     torch.cuda.set_device(0)
-    c = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    # ONE explicit stream for everything in this module: torch fills / reads the device buffers on it (it is made
+    # the current stream) and the library launches on it, so a kernel is ordered after the fill of its inputs on the
+    # device.  (torch's default stream has handle 0, which the C ABI reads as "create a private stream".)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0 and torch.cuda.current_stream().cuda_stream == stream.cuda_stream
+    c = capi.Context(0, stream.cuda_stream)
     yield c
     c.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())
 
 
 def oparams(oracle, opt, sim):
@@ -260,6 +267,15 @@ def test_price_paths_empty_shard_and_errors(ctx):
         ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(100, 3, 16))
     with pytest.raises(capi.McamdError):
         ctx.price_paths(capi.make_option(**BENCH, Tk=3), capi.make_sim(100, 3, capi.F64))
+    # fp64 keeps the path exponent in an int32 (fast64.hpp ExpAcc): a job whose log-returns leave the range of a
+    # double is refused, not wrapped (the boundary: |drift| + 8.6 vol < 700 per step)
+    with pytest.raises(capi.McamdError, match="exponent range"):
+        ctx.price_paths(capi.make_option(100.0, 1.0, 100.0, 0.1, 90.0), capi.make_sim(100, 1, capi.F64))
+    ok = ctx.price_paths(capi.make_option(100.0, 1.0, 100.0, 0.1, 20.0), capi.make_sim(100_000, 1, capi.F64))
+    assert math.isfinite(ok.sum) or math.isinf(ok.sum)     # sigma = 2000 %: huge payoffs, but no wrap to negative
+    assert ok.sum > 0
+    res32 = ctx.price_paths(capi.make_option(100.0, 1.0, 100.0, 0.1, 90.0), capi.make_sim(100, 1, capi.F32))
+    assert res32.n == 100                                    # fp32 saturates in hardware: accepted
 
 
 @pytest.mark.parametrize("prec,n_steps", [(capi.F64, 1), (capi.F64, 252), (capi.F32, 1), (capi.F32, 252)])
@@ -591,6 +607,85 @@ def test_full_size_config4_properties(ctx):
         assert abs(V[s_].mean().item() - BS) < 5 * se_outer, s_
     assert math.isclose(res.sum, out.sum().item(), rel_tol=1e-9)
     assert res.kernel_ms > 100  # sanity: this is seconds of VALU work, not a skipped launch
+
+
+def test_option_dt_is_honoured_like_optiondata_step(ctx, oracle):
+    # the reference's multi-step kernels read the time step from OptionData.step (inc/trajectories.cuh:131,
+    # inc/nmc.cuh:28), not from T / N_STEPS: a caller-chosen dt changes the dynamics, the discount stays exp(-rT)
+    for prec in (capi.F64, capi.F32):
+        opt = capi.make_option(**BENCH, B=110.0, P1=2, P2=40, use_window=1, dt=0.0031)
+        sim = capi.make_sim(20_000, 60, prec, seed=3)
+        res = ctx.price_paths(opt, sim)
+        p = oparams(oracle, opt, sim)
+        p.dt = 0.0031
+        ref = oracle.mc_paths(p, prec, 0, sim.n_paths, threads=oracle.max_threads())
+        assert math.isclose(res.sum, ref["sum"], rel_tol=RT[prec] if prec == capi.F64 else 2e-3)
+        same = ctx.price_paths(capi.make_option(**BENCH, B=110.0, P1=2, P2=40, use_window=1), sim)
+        assert not math.isclose(same.sum, res.sum, rel_tol=1e-3)        # dt = T / n_steps is a different job
+        fin = capi.finalize(res.sum, res.sumsq, res.n, opt.r, opt.T)
+        assert math.isclose(fin.price, res.price, rel_tol=1e-15)
+    with pytest.raises(capi.McamdError):
+        ctx.price_paths(capi.make_option(**BENCH, dt=-1.0), capi.make_sim(10, 3, capi.F64))
+
+
+@pytest.mark.parametrize("prec", [capi.F32, capi.F64])
+@pytest.mark.parametrize("flags", [0, capi.FLAG_LOG_SPACE, capi.FLAG_ANTITHETIC])
+def test_closed_window_early_exit_changes_nothing(ctx, oracle, prec, flags):
+    # B = 120 > S0: nearly every step counts, P2 = 50 of 252 steps: the window closes for whole wavefronts long before
+    # maturity and they leave the step loop (mc_device.hpp simulate_sample).  The sums must equal the oracle's, which
+    # runs every step of every path.
+    opt = capi.make_option(**BENCH, B=120.0, P1=10, P2=50, use_window=1)
+    sim = capi.make_sim(30_000, 252, prec, seed=77, flags=flags)
+    res = ctx.price_paths(opt, sim)
+    p = oparams(oracle, opt, sim)
+    if flags & capi.FLAG_ANTITHETIC:
+        ref = oracle.mc_paths_vr(p, prec, 0, sim.n_paths, True, 0.0, threads=oracle.max_threads())
+        want = ref[0]
+    else:
+        want = oracle.mc_paths(p, prec, 0, sim.n_paths, threads=oracle.max_threads())["sum"]
+    tol = (1e-11 if flags == 0 else 1e-9) if prec == capi.F64 else 3e-3
+    assert math.isclose(res.sum, want, rel_tol=tol), (res.sum, want)
+    assert res.sum > 0
+
+
+def test_full_size_config4_reference_bullet_window(ctx, oracle):
+    # config 4 as hello.cu runs it: nested MC, 65 536 outer x 252 steps x 1000 inner, fp64, bullet window B = 120,
+    # P1 = 10, P2 = 50 (hello.cu:11-15).  Checks: (1) a sample of points against oracle_nmc_point (1e-11);
+    # (2) every point whose stored count is already beyond P2 prices to exactly 0 (inc/nmc.cuh:53,330);
+    # (3) the three strategies (wave per point, block per point, fused outer + inner) agree point for point;
+    # (4) the work figure: executed inner path-steps are far below the European-window count, because a wavefront
+    # leaves a point's step loop once every lane's count is beyond P2.
+    n_paths, n_steps, n_inner = 65_536, 252, 1000
+    opt = capi.make_option(**BENCH, B=120.0, P1=10, P2=50, use_window=1)
+    outer = capi.make_sim(n_paths, n_steps, capi.F64, seed=1234)
+    inner = capi.make_sim(n_paths, n_steps, capi.F64, seed=1235, n_paths_inner=n_inner)
+    traj, cnt = dev(n_paths * n_steps, torch.float64), dev(n_paths * n_steps, torch.int32)
+    ctx.simulate_trajectories(opt, outer, traj, cnt)
+    out_w, out_b = dev(n_paths * n_steps, torch.float64), dev(n_paths * n_steps, torch.float64)
+    rw = ctx.nmc_inner(opt, inner, traj, cnt, out_w, capi.STEP_MAJOR, capi.NMC_WAVE_PER_POINT)
+    rb = ctx.nmc_inner(opt, inner, traj, cnt, out_b, capi.STEP_MAJOR, capi.NMC_BLOCK_PER_POINT)
+    assert torch.allclose(out_w, out_b, rtol=1e-12, atol=1e-12) and math.isclose(rw.sum, rb.sum, rel_tol=1e-11)
+    traj_f, cnt_f, out_f = dev(n_paths * n_steps, torch.float64), dev(n_paths * n_steps, torch.int32), dev(n_paths * n_steps, torch.float64)
+    rf = ctx.nmc_fused(opt, inner, 1234, traj_f, cnt_f, out_f)
+    assert torch.equal(traj_f, traj) and torch.equal(cnt_f, cnt)
+    assert torch.equal(out_f, out_w) and math.isclose(rf.sum, rw.sum, rel_tol=1e-11)
+    V, S, C = out_w.view(n_steps, n_paths), traj.view(n_steps, n_paths), cnt.view(n_steps, n_paths)
+    dead = C > 50
+    assert dead.any() and (V[dead] == 0).all() and torch.isfinite(out_w).all() and (out_w >= 0).all()
+    # sampled points, spread over steps (early steps: long continuations; around P2: the window edge) and paths
+    p = oparams(oracle, opt, inner)
+    rng = np.random.default_rng(5)
+    pts = [(int(s_), int(q)) for s_ in (0, 1, 7, 20, 35, 44, 49, 50, 51, 60, 120, 251) for q in rng.integers(0, n_paths, 3)]
+    got = np.array([V[s_, q].item() for s_, q in pts])
+    want = np.array([oracle.nmc_point(p, capi.F64, q * n_steps + s_, s_, S[s_, q].item(), int(C[s_, q].item())) for s_, q in pts])
+    assert np.allclose(got, want, rtol=1e-11, atol=1e-12), np.abs(got - want).max()
+    assert (want > 0).sum() >= 6        # the sample does exercise live points
+    european_steps = n_paths * n_inner * (n_steps * (n_steps - 1) // 2)
+    assert 0 < rw.work_steps < 0.2 * european_steps and rw.work_steps == rf.work_steps
+    # tower property at step 0: the mean inner price estimates the bullet option's value (reference CPU: 4.839 at
+    # 100 steps; here 252 steps — compare with the engine's own outer estimate instead)
+    direct = ctx.price_paths(opt, capi.make_sim(4_000_000, n_steps, capi.F64, seed=99))
+    assert abs(V[0].mean().item() - direct.price) < 5 * (direct.std_err + 10.0 / math.sqrt(n_paths * n_inner) + 8.0 / math.sqrt(n_paths))
 
 
 def test_full_size_config5_rank_shard_properties(ctx):

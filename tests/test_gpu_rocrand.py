@@ -42,9 +42,12 @@ def rr(tmp_path_factory):
 @pytest.fixture(scope="module")
 def ctx():
     torch.cuda.set_device(0)
-    c = capi.Context(0)
+    stream = torch.cuda.Stream()          # one explicit stream shared by torch and the library (see test_gpu_parity.py)
+    torch.cuda.set_stream(stream)
+    c = capi.Context(0, stream.cuda_stream)
     yield c
     c.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())
 
 
 def test_bulk_fill_equals_rocrand_subsequence_zero(ctx, rr):

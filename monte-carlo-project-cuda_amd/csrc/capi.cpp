@@ -58,6 +58,8 @@ struct mcamd_ctx {
     double *d_partials = nullptr;  // one record (2 or 5 doubles) per block
     uint64_t partial_capacity = 0; // in doubles
     double *d_out = nullptr;       // 8 doubles
+    unsigned long long *d_queue = nullptr;  // task counter of the wave-per-point nested-MC kernel
+    uint32_t compute_units = 0;
     double *h_out = nullptr;       // pinned, 8 doubles
     // asynchronous calls: a ring of event pairs around the simulation kernel of the last kRing enqueues
     static constexpr uint32_t kRing = 64;
@@ -303,6 +305,8 @@ int mcamd_ctx_create(int device, void *hip_stream, mcamd_ctx **out)
         if (e == hipSuccess) e = hipEventCreate(&ctx->ring1[i]);
     }
     if (e == hipSuccess) e = hipMalloc(&ctx->d_out, 8 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_queue, 64);
+    ctx->compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
     if (e == hipSuccess) e = hipHostMalloc(&ctx->h_out, 8 * sizeof(double), hipHostMallocDefault);
     if (e != hipSuccess) {
         mcamd_ctx_destroy(ctx);
@@ -319,6 +323,7 @@ int mcamd_ctx_destroy(mcamd_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -579,11 +584,12 @@ int mcamd_nmc_inner(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
     job.n_inner = sim->n_paths_inner;
     job.discount = std::exp(-opt->r * opt->T);
     job.n_points = n_points;
+    job.compute_units = ctx->compute_units;
     const uint32_t grid = mcamd::nmc_grid(job, variant);
     if (int rc = ensure_partials(ctx, grid, mcamd::kNmcRecord)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    HIP_TRY(mcamd::launch_nmc_inner(job, layout, variant, d_prices, d_counts, d_point_prices, ctx->d_partials, grid,
-                                    ctx->stream));
+    HIP_TRY(mcamd::launch_nmc_inner(job, layout, variant, d_prices, d_counts, d_point_prices, ctx->d_partials,
+                                    ctx->d_queue, grid, ctx->stream));
     if (int rc = finish(ctx, grid, res, mcamd::kNmcRecord)) return rc;
     res->n = n_points;
     res->price = n_points ? res->sum / static_cast<double>(n_points) : 0.0;  // mean point price (diagnostic)
@@ -617,6 +623,7 @@ int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
     job.n_inner = sim->n_paths_inner;
     job.discount = std::exp(-opt->r * opt->T);
     job.n_points = n_points;
+    job.compute_units = ctx->compute_units;
     const uint32_t grid = mcamd::nmc_fused_grid(job);
     if (int rc = ensure_partials(ctx, grid, mcamd::kNmcRecord)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));

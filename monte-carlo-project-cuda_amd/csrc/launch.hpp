@@ -54,12 +54,15 @@ struct NmcJob {
     uint32_t n_inner;
     double discount;         // exp(-r T)
     uint64_t n_points;       // n_local * n_steps
+    uint32_t compute_units;  // of the device the job runs on (sizes the persistent grid of the wave-per-point kernel)
 };
 // the nested-MC kernels write 3-double block records: {sum of point prices, sum of squares, wave-steps executed}
 constexpr int kNmcRecord = 3;
 uint32_t nmc_grid(const NmcJob &job, int variant);
+// d_queue: one zeroed 64-bit word (the wave-per-point kernel's task counter; the launcher zeroes it on `stream`)
 hipError_t launch_nmc_inner(const NmcJob &job, int layout, int variant, const void *d_prices, const int32_t *d_counts,
-                            void *d_point_prices, double *d_partials, uint32_t grid, hipStream_t stream);
+                            void *d_point_prices, double *d_partials, unsigned long long *d_queue, uint32_t grid,
+                            hipStream_t stream);
 
 uint32_t nmc_fused_grid(const NmcJob &job);
 hipError_t launch_nmc_fused(const NmcJob &job, uint64_t outer_seed, int layout, void *d_prices, int32_t *d_counts,

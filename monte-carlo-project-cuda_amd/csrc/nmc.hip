@@ -12,10 +12,18 @@
 //
 // WAVE_PER_POINT is the gfx950-shaped one: a point is a task for ONE wavefront; its 64 lanes
 // stride over the inner paths and the point's sum is a pure wave64 shuffle reduction — no LDS,
-// no barrier, no atomics, against the reference's 1024-thread block + 5-barrier tree per task.
-// Tasks are ordered step-major, so the long tasks (small step, many remaining steps) are issued
+// no barrier, against the reference's 1024-thread block + 5-barrier tree per task.
+// Tasks are ordered step-major, so the long tasks (small step, many remaining steps) come
 // first and the short ones fill the tail.  A point whose count already exceeds P2 can never pay
-// (inc/nmc.cuh:53,330) and is skipped by the whole wave.
+// (inc/nmc.cuh:53,330) and is skipped by the whole wave.  Tasks are handed out dynamically: the
+// grid is persistent (a few workgroups per CU) and every wavefront pulls the next chunk of kNmcChunk
+// consecutive tasks from one device-scope counter.  With the bullet window task lengths differ widely
+// (a wavefront runs until its LAST lane's window closes), and under a static assignment a finished
+// wavefront idles until the slowest wavefront of its workgroup retires (measured: VALU 85 % busy,
+// profiles/r02c_nmc_pmc_per_kernel.json); pulled tasks keep every wavefront busy until the queue is empty.
+// One returning atomic per chunk: 4M dequeues over ~0.5 s, far below the ~88 per microsecond one
+// counter sustains (MI355X_MICROARCH.md, dequeue).  Every wavefront leaves its loop on the first
+// index past the end, so the grid always drains.
 // Each inner path restarts from the stored (St, count); the reference's carry-over between
 // successive inner paths of one thread is a defect and is not reproduced, and the
 // output is written, not atomically added to unzeroed memory.
@@ -48,38 +56,46 @@ __device__ __forceinline__ uint64_t point_index(const NmcArgs<T> &a, uint64_t ta
     return LAYOUT == MCAMD_STEP_MAJOR ? task : path * a.n_steps + step;
 }
 
+constexpr uint32_t kNmcChunk = 4;  // tasks per dequeue: same step, adjacent paths
+
 template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE>
-__global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *__restrict__ partials)
+__global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *__restrict__ partials,
+                                                          unsigned long long *__restrict__ queue)
 {
-    constexpr int kWaves = kBlock / kWave;
     const MathCtx<T> m = MathCtx<T>::init();
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
-    const uint64_t wave_stride = static_cast<uint64_t>(gridDim.x) * kWaves;
     double rec[kNmcRecord] = {0.0, 0.0, 0.0};  // sum of point prices, sum of squares, wave-steps executed (lane 0)
-    for (uint64_t task = static_cast<uint64_t>(blockIdx.x) * kWaves + wave; task < a.n_points; task += wave_stride) {
-        uint32_t step;
-        uint64_t path;
-        const uint64_t idx = point_index<T, WINDOW, LAYOUT>(a, task, step, path);
-        const T St0 = a.prices[idx];
-        const int32_t cnt0 = WINDOW ? a.counts[idx] : 0;
-        const uint32_t remaining = a.n_steps - (step + 1);
-        const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
-        double acc = 0.0;
-        uint32_t steps_run = 0;
-        if (!WINDOW || cnt0 <= a.c.P2) {
-            const T ls = (WINDOW && LOGSPACE) ? log_ratio(St0, a.c.S_start) : T(0);
-            for (uint32_t j = lane; j < a.n_inner; j += kWave)
-                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(a.c, m, a.seed, point_id * a.n_inner + j,
-                                                                               St0, cnt0, remaining, ls, &steps_run));
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            const double price = acc * a.scale;
-            a.out[idx] = static_cast<T>(price);
-            rec[0] += price;
-            rec[1] = __builtin_fma(price, price, rec[1]);
-            rec[2] += static_cast<double>(steps_run);   // lane 0 takes part in every pass over the inner paths
+    for (;;) {
+        unsigned long long first = 0;
+        if (lane == 0) first = atomicAdd(queue, static_cast<unsigned long long>(kNmcChunk));
+        const uint64_t base = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(first >> 32))) << 32) |
+                              __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(first));
+        if (base >= a.n_points) break;
+        const uint64_t end = base + kNmcChunk < a.n_points ? base + kNmcChunk : a.n_points;
+        for (uint64_t task = base; task < end; ++task) {
+            uint32_t step;
+            uint64_t path;
+            const uint64_t idx = point_index<T, WINDOW, LAYOUT>(a, task, step, path);
+            const T St0 = a.prices[idx];
+            const int32_t cnt0 = WINDOW ? a.counts[idx] : 0;
+            const uint32_t remaining = a.n_steps - (step + 1);
+            const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
+            double acc = 0.0;
+            uint32_t steps_run = 0;
+            if (!WINDOW || cnt0 <= a.c.P2) {
+                const T ls = (WINDOW && LOGSPACE) ? log_ratio(St0, a.c.S_start) : T(0);
+                for (uint32_t j = lane; j < a.n_inner; j += kWave)
+                    acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(
+                        a.c, m, a.seed, point_id * a.n_inner + j, St0, cnt0, remaining, ls, &steps_run));
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                const double price = acc * a.scale;
+                a.out[idx] = static_cast<T>(price);
+                rec[0] += price;
+                rec[1] = __builtin_fma(price, price, rec[1]);
+                rec[2] += static_cast<double>(steps_run);   // lane 0 takes part in every pass over the inner paths
+            }
         }
     }
     block_sumN<kBlock, kNmcRecord>(rec);
@@ -176,7 +192,16 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
     // ---- phase 2: inner stage over the owned points, one wavefront per point, long tasks first ----
     double rec[kNmcRecord] = {0.0, 0.0, 0.0};
     const uint64_t n_tasks = n_owned * a.n_steps;
-    for (uint64_t task = wave; task < n_tasks; task += kWaves) {
+    // the workgroup's wavefronts pull its tasks from a counter in LDS (same reason as nmc_wave_kernel's queue)
+    __shared__ unsigned int s_next;
+    if (threadIdx.x == 0) s_next = 0;
+    __syncthreads();
+    (void)wave;
+    for (;;) {
+        unsigned int mine = 0;
+        if (lane == 0) mine = atomicAdd(&s_next, 1u);
+        const uint64_t task = __builtin_amdgcn_readfirstlane(mine);
+        if (task >= n_tasks) break;
         const uint32_t step = static_cast<uint32_t>(task / n_owned);
         const uint64_t path = blockIdx.x + (task - static_cast<uint64_t>(step) * n_owned) * gridDim.x;
         const uint64_t idx = LAYOUT == MCAMD_STEP_MAJOR ? static_cast<uint64_t>(step) * a.n_local + path
@@ -211,8 +236,9 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
 
 uint32_t nmc_fused_grid(const NmcJob &job)
 {
-    // enough workgroups to fill the chip several times over, few enough that each owns whole paths
-    const uint64_t want = job.path.n_local < 8192 ? job.path.n_local : 8192;
+    // a workgroup owns whole outer paths; many small workgroups (two paths each at BASELINE configs[3]) keep the
+    // end of the launch short, since a workgroup's work depends on when ITS paths' windows close
+    const uint64_t want = job.path.n_local < 32768 ? job.path.n_local : 32768;
     return static_cast<uint32_t>(want < 1 ? 1 : want);
 }
 
@@ -232,20 +258,26 @@ static void launch_fused_variant(const NmcArgs<T> &a, uint64_t outer_seed, bool 
 uint32_t nmc_grid(const NmcJob &job, int variant)
 {
     if (variant == MCAMD_NMC_BLOCK_PER_POINT) return clamp_grid(job.n_points);
-    return clamp_grid((job.n_points + (kBlock / kWave) - 1) / (kBlock / kWave));
+    // wave per point: persistent grid, 8 workgroups per CU (all that can be resident), tasks pulled from a queue
+    const uint64_t per_block = static_cast<uint64_t>(kBlock / kWave) * kNmcChunk;
+    const uint64_t need = (job.n_points + per_block - 1) / per_block;
+    const uint64_t resident = static_cast<uint64_t>(job.compute_units ? job.compute_units : 256) * 8;
+    return static_cast<uint32_t>(need < 1 ? 1 : (need < resident ? need : resident));
 }
 
 template <typename T, bool WINDOW, int LAYOUT>
-static void launch_variant(const NmcArgs<T> &a, int variant, bool logspace, double *d_partials, uint32_t grid,
-                           hipStream_t stream)
+static void launch_variant(const NmcArgs<T> &a, int variant, bool logspace, double *d_partials,
+                           unsigned long long *d_queue, uint32_t grid, hipStream_t stream)
 {
     const dim3 g(grid), b(kBlock);
     if (variant == MCAMD_NMC_BLOCK_PER_POINT) {
         if (logspace) hipLaunchKernelGGL((nmc_block_kernel<T, WINDOW, LAYOUT, true>), g, b, 0, stream, a, d_partials);
         else hipLaunchKernelGGL((nmc_block_kernel<T, WINDOW, LAYOUT, false>), g, b, 0, stream, a, d_partials);
     } else {
-        if (logspace) hipLaunchKernelGGL((nmc_wave_kernel<T, WINDOW, LAYOUT, true>), g, b, 0, stream, a, d_partials);
-        else hipLaunchKernelGGL((nmc_wave_kernel<T, WINDOW, LAYOUT, false>), g, b, 0, stream, a, d_partials);
+        if (logspace)
+            hipLaunchKernelGGL((nmc_wave_kernel<T, WINDOW, LAYOUT, true>), g, b, 0, stream, a, d_partials, d_queue);
+        else
+            hipLaunchKernelGGL((nmc_wave_kernel<T, WINDOW, LAYOUT, false>), g, b, 0, stream, a, d_partials, d_queue);
     }
 }
 
@@ -295,28 +327,33 @@ hipError_t launch_nmc_fused(const NmcJob &job, uint64_t outer_seed, int layout, 
 
 template <typename T>
 static hipError_t launch_nmc_t(const NmcJob &job, int layout, int variant, const void *d_prices,
-                               const int32_t *d_counts, void *d_point_prices, double *d_partials, uint32_t grid,
-                               hipStream_t stream)
+                               const int32_t *d_counts, void *d_point_prices, double *d_partials,
+                               unsigned long long *d_queue, uint32_t grid, hipStream_t stream)
 {
     const NmcArgs<T> a = make_args<T>(job, d_prices, d_counts, d_point_prices);
-    const bool w = job.path.window;
+    const bool w = job.path.window, ls = job.path.logspace;
     if (layout == MCAMD_STEP_MAJOR) {
-        if (w) launch_variant<T, true, MCAMD_STEP_MAJOR>(a, variant, job.path.logspace, d_partials, grid, stream);
-        else launch_variant<T, false, MCAMD_STEP_MAJOR>(a, variant, job.path.logspace, d_partials, grid, stream);
+        if (w) launch_variant<T, true, MCAMD_STEP_MAJOR>(a, variant, ls, d_partials, d_queue, grid, stream);
+        else launch_variant<T, false, MCAMD_STEP_MAJOR>(a, variant, ls, d_partials, d_queue, grid, stream);
     } else {
-        if (w) launch_variant<T, true, MCAMD_PATH_MAJOR>(a, variant, job.path.logspace, d_partials, grid, stream);
-        else launch_variant<T, false, MCAMD_PATH_MAJOR>(a, variant, job.path.logspace, d_partials, grid, stream);
+        if (w) launch_variant<T, true, MCAMD_PATH_MAJOR>(a, variant, ls, d_partials, d_queue, grid, stream);
+        else launch_variant<T, false, MCAMD_PATH_MAJOR>(a, variant, ls, d_partials, d_queue, grid, stream);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_nmc_inner(const NmcJob &job, int layout, int variant, const void *d_prices, const int32_t *d_counts,
-                            void *d_point_prices, double *d_partials, uint32_t grid, hipStream_t stream)
+                            void *d_point_prices, double *d_partials, unsigned long long *d_queue, uint32_t grid,
+                            hipStream_t stream)
 {
-    return job.path.precision == 32
-               ? launch_nmc_t<float>(job, layout, variant, d_prices, d_counts, d_point_prices, d_partials, grid, stream)
-               : launch_nmc_t<double>(job, layout, variant, d_prices, d_counts, d_point_prices, d_partials, grid,
-                                      stream);
+    if (variant == MCAMD_NMC_WAVE_PER_POINT) {
+        const hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(unsigned long long), stream);
+        if (e != hipSuccess) return e;
+    }
+    return job.path.precision == 32 ? launch_nmc_t<float>(job, layout, variant, d_prices, d_counts, d_point_prices,
+                                                          d_partials, d_queue, grid, stream)
+                                    : launch_nmc_t<double>(job, layout, variant, d_prices, d_counts, d_point_prices,
+                                                           d_partials, d_queue, grid, stream);
 }
 
 }  // namespace mcamd

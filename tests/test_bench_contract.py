@@ -77,7 +77,7 @@ def test_bare_gpus_n_fails_loudly_without_n_devices():
 def test_bench_emits_one_json_line_with_roofline_and_cpu_baseline():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                           "--paths", "1000000", "--cpu-sample-paths", "20000", "--no-store-roofline",
-                          "--no-accuracy-demo"], capture_output=True, text=True, timeout=600)
+                          "--no-accuracy", "--no-sweep"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -96,3 +96,7 @@ def test_bench_emits_one_json_line_with_roofline_and_cpu_baseline():
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0
     assert d["within_3se"] in (True, False) and abs(d["price"] - 13.2697) < 0.1
+    dev = d["device"]
+    assert dev["arch"].startswith("gfx950") and dev["compute_units"] >= 200 and dev["hbm_free_gb"] > 100
+    assert rl["valu_slots_per_path_step"] and "stale" not in rl     # the slot count describes the loaded library
+    assert d["cfg1"]["closed_form"]["evals"] == 1_000_000 and d["cfg1"]["serial_mc_port_f64"]["paths"] == 1_000_000

@@ -271,9 +271,8 @@ def test_price_paths_empty_shard_and_errors(ctx):
     # double is refused, not wrapped (the boundary: |drift| + 8.6 vol < 700 per step)
     with pytest.raises(capi.McamdError, match="exponent range"):
         ctx.price_paths(capi.make_option(100.0, 1.0, 100.0, 0.1, 90.0), capi.make_sim(100, 1, capi.F64))
-    ok = ctx.price_paths(capi.make_option(100.0, 1.0, 100.0, 0.1, 20.0), capi.make_sim(100_000, 1, capi.F64))
-    assert math.isfinite(ok.sum) or math.isinf(ok.sum)     # sigma = 2000 %: huge payoffs, but no wrap to negative
-    assert ok.sum > 0
+    ok = ctx.price_paths(capi.make_option(100.0, 1.0, 100.0, 0.1, 5.0), capi.make_sim(100_000, 1, capi.F64))
+    assert math.isfinite(ok.sum) and ok.sum > 0              # sigma = 500 %: rare, huge payoffs; nothing wraps
     res32 = ctx.price_paths(capi.make_option(100.0, 1.0, 100.0, 0.1, 90.0), capi.make_sim(100, 1, capi.F32))
     assert res32.n == 100                                    # fp32 saturates in hardware: accepted
 

@@ -13,17 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for key in ("price_kernel<double, false, false, 0>", "price_kernel<double, false, true, 0>",
-                "price_kernel<double, false, false, 3>", "price_kernel<double, true, false, 0>",
-                "price_kernel<float, false, false, 0>",
-                "store_kernel<float, false, 0, true>", "final_reduce_kernel"):
-        if key in name:
-            return key
-    return name[:60]
+    """mcamd::kernel<template args> without the parameter list (kernel names in rocprofv3 CSVs are demangled)."""
+    import re
+    m = re.search(r"mcamd::(\w+(?:<[^()]*?>)?)\(", name)
+    return m.group(1) if m else name[:60]
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -35,7 +32,7 @@ def main():
             for row in csv.DictReader(fh):
                 agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     out = {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"dispatches": max(len(v) for v in cs.values())}
-           for k, cs in agg.items() if "mcamd" in k or "kernel<" in k}
+           for k, cs in agg.items() if "kernel" in k}
     with open(os.path.join(dst, f"{tag}_pmc_per_kernel.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))

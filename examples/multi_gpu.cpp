@@ -28,10 +28,15 @@ int main(int argc, char **argv)
     sim.n_steps = n_steps; sim.seed = 1234; sim.precision = MCAMD_F64;
 
     mcamd_result res;
-    mcamd_group_price_paths(group, &opt, &sim, &res);   // warm-up: RCCL rings, code objects
+    if (mcamd_group_price_paths(group, &opt, &sim, &res) != MCAMD_OK) {   // warm-up: RCCL rings, code objects
+        std::fprintf(stderr, "mcamd (warm-up): %s\n", mcamd_last_error());
+        mcamd_group_destroy(group);
+        return 1;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     if (mcamd_group_price_paths(group, &opt, &sim, &res) != MCAMD_OK) {
         std::fprintf(stderr, "mcamd: %s\n", mcamd_last_error());
+        mcamd_group_destroy(group);
         return 1;
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

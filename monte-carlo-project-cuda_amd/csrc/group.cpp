@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -34,10 +35,22 @@ struct Rccl {
 };
 
 Rccl g_rccl;
+std::once_flag g_rccl_once;
+int g_rccl_status = MCAMD_OK;
+std::string g_rccl_error;
 
+int load_rccl_once();
+
+// Loads RCCL exactly once per process, whichever thread asks first; later callers get the recorded outcome.
 int load_rccl()
 {
-    if (g_rccl.handle) return MCAMD_OK;
+    std::call_once(g_rccl_once, [] { g_rccl_status = load_rccl_once(); if (g_rccl_status) g_rccl_error = mcamd_last_error(); });
+    if (g_rccl_status) return mcamd_set_error_(g_rccl_status, g_rccl_error.c_str());
+    return MCAMD_OK;
+}
+
+int load_rccl_once()
+{
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     for (const char *n : names) {
@@ -81,6 +94,20 @@ struct mcamd_group {
     std::vector<double *> d_stats;  // 8 doubles per device
     std::vector<ncclComm_t> comms;
 };
+
+namespace {
+
+// waits for everything enqueued on the group's streams (error paths: nothing may still be running when the call
+// returns); errors of the wait itself are dropped, the caller is already reporting one
+void drain(mcamd_group *g)
+{
+    for (size_t i = 0; i < g->devices.size(); ++i) {
+        if (hipSetDevice(g->devices[i]) == hipSuccess && g->streams[i]) (void)hipStreamSynchronize(g->streams[i]);
+        (void)hipGetLastError();
+    }
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -162,20 +189,37 @@ int mcamd_group_price_paths(mcamd_group *g, const mcamd_option *opt, const mcamd
         s.path_offset = sim->path_offset + static_cast<uint64_t>(i) * base + (static_cast<uint64_t>(i) < rem ? i : rem);
         s.n_paths_local = base + (static_cast<uint64_t>(i) < rem ? 1 : 0);
         // asynchronous: every device starts its shard before any host wait
-        if (int rc = mcamd_price_paths_enqueue(g->ctx[i], opt, &s, g->d_stats[i])) return rc;
+        if (int rc = mcamd_price_paths_enqueue(g->ctx[i], opt, &s, g->d_stats[i])) {
+            const std::string why = mcamd_last_error();
+            drain(g);   // shards already enqueued on devices 0..i-1 must not outlive the failed call
+            return mcamd_set_error_(rc, why.c_str());
+        }
     }
-    // the one collective of the path: (sum, sumsq, sum_c, sum_cc, sum_yc, n) summed over the devices
+    // the one collective of the path: (sum, sumsq, sum_c, sum_cc, sum_yc, n) summed over the devices.  A group
+    // that was started is always ended, whatever an AllReduce returned, so a failed call cannot leave RCCL's
+    // thread-local group open for the next one.
     ncclResult_t ne = g_rccl.GroupStart();
-    for (int i = 0; i < R && ne == ncclSuccess; ++i)
-        ne = g_rccl.AllReduce(g->d_stats[i], g->d_stats[i], 6, ncclDouble, ncclSum, g->comms[i], g->streams[i]);
-    if (ne == ncclSuccess) ne = g_rccl.GroupEnd();
-    if (ne != ncclSuccess) return nccl_fail(ne, "ncclAllReduce");
+    if (ne == ncclSuccess) {
+        ncclResult_t first = ncclSuccess;
+        for (int i = 0; i < R && first == ncclSuccess; ++i)
+            first = g_rccl.AllReduce(g->d_stats[i], g->d_stats[i], 6, ncclDouble, ncclSum, g->comms[i], g->streams[i]);
+        const ncclResult_t end = g_rccl.GroupEnd();
+        ne = first != ncclSuccess ? first : end;
+    }
+    if (ne != ncclSuccess) {
+        drain(g);
+        return nccl_fail(ne, "ncclAllReduce");
+    }
     double stats[8] = {0};
     float kernel_ms = 0.0f;
-    for (int i = 0; i < R; ++i) {
+    hipError_t sync_err = hipSuccess;
+    for (int i = 0; i < R; ++i) {   // every device is waited for, also after one of them has failed
         hipError_t e = hipSetDevice(g->devices[i]);
         if (e == hipSuccess) e = hipStreamSynchronize(g->streams[i]);
-        if (e != hipSuccess) return hip_fail(e, "group synchronise");
+        if (e != hipSuccess && sync_err == hipSuccess) sync_err = e;
+    }
+    if (sync_err != hipSuccess) return hip_fail(sync_err, "group synchronise");
+    for (int i = 0; i < R; ++i) {
         float ms = 0.0f;
         if (int rc = mcamd_enqueued_kernel_ms(g->ctx[i], 1, &ms)) return rc;
         kernel_ms = std::fmax(kernel_ms, ms);

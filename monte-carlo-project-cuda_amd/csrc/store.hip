@@ -34,21 +34,99 @@ struct StoreArgs {
 };
 
 // One step row: the thread's V consecutive paths.  Streaming data: written once, never re-read
-// by this kernel, so the stores are non-temporal.
-template <typename E, int V, bool VEC>
-__device__ __forceinline__ void store_row(E *row_base, uint64_t base, const E (&val)[V], int n_valid)
+// by this kernel, so the stores are non-temporal (measured against plain stores on the full-size
+// job: 15.9 vs 16.5 ms, profiles/r02_store_variants.jsonl).  `row` is wave-uniform and `off` is the
+// thread's element offset inside a row: with a 32-bit `off` the store takes the scalar-base +
+// vector-offset form, and stepping to the next row costs the vector ALU nothing.
+template <typename E, int V, bool VEC, typename OFF>
+__device__ __forceinline__ void store_row(E *__restrict__ row, OFF off, const E (&val)[V], int n_valid)
 {
+    // byte offset in OFF's own width: a 32-bit offset zero-extended onto a uniform base is what selects the
+    // scalar-base addressing form
+    char *const p0 = reinterpret_cast<char *>(row) + static_cast<OFF>(off * static_cast<OFF>(sizeof(E)));
     if (VEC) {
         using VT = E __attribute__((ext_vector_type(V)));
         VT pack;
 #pragma unroll
         for (int p = 0; p < V; ++p) pack[p] = val[p];
-        __builtin_nontemporal_store(pack, reinterpret_cast<VT *>(row_base + base));
+        __builtin_nontemporal_store(pack, reinterpret_cast<VT *>(p0));
     } else {
 #pragma unroll
         for (int p = 0; p < V; ++p)
-            if (p < n_valid) __builtin_nontemporal_store(val[p], row_base + base + p);
+            if (p < n_valid) __builtin_nontemporal_store(val[p], reinterpret_cast<E *>(p0) + p);
     }
+}
+
+// The paths of one thread (V consecutive ones starting at `base`) through all steps.  OFF = uint32_t when a whole
+// row is addressable with 32 bits (every realistic trajectory buffer), uint64_t otherwise.
+template <typename T, bool WINDOW, int LAYOUT, bool VEC, typename OFF>
+__device__ __forceinline__ void store_group(const StoreArgs<T> &a, const MathCtx<T> &m, uint64_t base, double &s,
+                                            double &s2)
+{
+    constexpr int V = 16 / sizeof(T);
+    constexpr int NB = Normals<T>::kPerBlock;
+    const StepConsts<T> &c = a.c;
+    const uint32_t n_full = c.n_sim / NB;         // Philox blocks whose NB steps are all simulated
+    const uint32_t rem = c.n_sim - n_full * NB;   // steps of the last, partial block
+    const OFF off = static_cast<OFF>(base);
+    const int n_valid =
+        VEC ? V : ((a.n_local - base >= static_cast<uint64_t>(V)) ? V : static_cast<int>(a.n_local - base));
+    T St[V];
+    PathState<T> ps[V];
+    int32_t cnt[V];
+#pragma unroll
+    for (int p = 0; p < V; ++p) {
+        St[p] = c.S_start;
+        ps[p] = PathState<T>::start(c.S_start);
+        cnt[p] = c.Ik;
+    }
+    auto advance = [&](const Exponents<T>(&nrm)[V], int j, uint32_t step) {
+#pragma unroll
+        for (int p = 0; p < V; ++p) {
+            ps[p].step(nrm[p].x[j], m);
+            St[p] = ps[p].value(m);
+            if (WINDOW) cnt[p] += (c.B > St[p]) ? 1 : 0;
+        }
+        if (LAYOUT == MCAMD_STEP_MAJOR) {
+            const uint64_t row = static_cast<uint64_t>(step) * a.n_local;   // wave-uniform: scalar unit
+            store_row<T, V, VEC, OFF>(a.traj + row, off, St, n_valid);
+            if (WINDOW && a.counts) store_row<int32_t, V, VEC, OFF>(a.counts + row, off, cnt, n_valid);
+        } else {
+#pragma unroll
+            for (int p = 0; p < V; ++p)
+                if (p < n_valid) {
+                    const uint64_t idx = (base + p) * c.n_sim + step;
+                    a.traj[idx] = St[p];
+                    if (WINDOW && a.counts) a.counts[idx] = cnt[p];
+                }
+        }
+    };
+    for (uint32_t k = 0; k < n_full; ++k) {
+        Exponents<T> nrm[V];
+#pragma unroll
+        for (int p = 0; p < V; ++p) nrm[p].fill(m, c, a.seed, a.path_offset + base + p, k);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) advance(nrm, j, k * NB + j);
+    }
+    if (rem) {
+        Exponents<T> nrm[V];
+#pragma unroll
+        for (int p = 0; p < V; ++p) nrm[p].fill(m, c, a.seed, a.path_offset + base + p, n_full);
+#pragma unroll
+        for (int j = 0; j < NB - 1; ++j)
+            if (static_cast<uint32_t>(j) < rem) advance(nrm, j, n_full * NB + j);
+    }
+    T pay[V];
+#pragma unroll
+    for (int p = 0; p < V; ++p) {
+        pay[p] = payoff<T, WINDOW>(St[p], cnt[p], c);
+        if (p < n_valid) {
+            const double pd = static_cast<double>(pay[p]);
+            s += pd;
+            s2 = __builtin_fma(pd, pd, s2);
+        }
+    }
+    if (a.payoffs) store_row<T, V, VEC, OFF>(a.payoffs, off, pay, n_valid);
 }
 
 // VEC: every row is 16-byte aligned and n_local is a multiple of V, so each thread's group is full
@@ -58,73 +136,14 @@ template <typename T, bool WINDOW, int LAYOUT, bool VEC>
 __global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *__restrict__ partials)
 {
     constexpr int V = 16 / sizeof(T);
-    constexpr int NB = Normals<T>::kPerBlock;
-    const StepConsts<T> &c = a.c;
     const MathCtx<T> m = MathCtx<T>::init();
     const uint64_t n_groups = (a.n_local + V - 1) / V;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    const uint32_t n_full = c.n_sim / NB;         // Philox blocks whose NB steps are all simulated
-    const uint32_t rem = c.n_sim - n_full * NB;   // steps of the last, partial block
+    const bool narrow = a.n_local + V <= 0xffffffffull / 8;   // a row's byte offsets (prices or counts) fit 32 bits
     double s = 0.0, s2 = 0.0;
-
     for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; g < n_groups; g += stride) {
-        const uint64_t base = g * V;
-        const int n_valid =
-            VEC ? V : ((a.n_local - base >= static_cast<uint64_t>(V)) ? V : static_cast<int>(a.n_local - base));
-        T St[V];
-        PathState<T> ps[V];
-        int32_t cnt[V];
-#pragma unroll
-        for (int p = 0; p < V; ++p) {
-            St[p] = c.S_start;
-            ps[p] = PathState<T>::start(c.S_start);
-            cnt[p] = c.Ik;
-        }
-        auto advance = [&](const Exponents<T>(&nrm)[V], int j, uint32_t step) {
-#pragma unroll
-            for (int p = 0; p < V; ++p) {
-                ps[p].step(nrm[p].x[j], m);
-                St[p] = ps[p].value(m);
-                if (WINDOW) cnt[p] += (c.B > St[p]) ? 1 : 0;
-            }
-            if (LAYOUT == MCAMD_STEP_MAJOR) {
-                const uint64_t row = static_cast<uint64_t>(step) * a.n_local;
-                store_row<T, V, VEC>(a.traj + row, base, St, n_valid);
-                if (WINDOW && a.counts) store_row<int32_t, V, VEC>(a.counts + row, base, cnt, n_valid);
-            } else {
-#pragma unroll
-                for (int p = 0; p < V; ++p)
-                    if (p < n_valid) {
-                        const uint64_t idx = (base + p) * c.n_sim + step;
-                        a.traj[idx] = St[p];
-                        if (WINDOW && a.counts) a.counts[idx] = cnt[p];
-                    }
-            }
-        };
-        for (uint32_t k = 0; k < n_full; ++k) {
-            Exponents<T> nrm[V];
-#pragma unroll
-            for (int p = 0; p < V; ++p) nrm[p].fill(m, c, a.seed, a.path_offset + base + p, k);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) advance(nrm, j, k * NB + j);
-        }
-        if (rem) {
-            Exponents<T> nrm[V];
-#pragma unroll
-            for (int p = 0; p < V; ++p) nrm[p].fill(m, c, a.seed, a.path_offset + base + p, n_full);
-#pragma unroll
-            for (int j = 0; j < NB - 1; ++j)
-                if (static_cast<uint32_t>(j) < rem) advance(nrm, j, n_full * NB + j);
-        }
-#pragma unroll
-        for (int p = 0; p < V; ++p)
-            if (p < n_valid) {
-                const T pay = payoff<T, WINDOW>(St[p], cnt[p], c);
-                if (a.payoffs) a.payoffs[base + p] = pay;
-                const double pd = static_cast<double>(pay);
-                s += pd;
-                s2 = __builtin_fma(pd, pd, s2);
-            }
+        if (narrow) store_group<T, WINDOW, LAYOUT, VEC, uint32_t>(a, m, g * V, s, s2);
+        else store_group<T, WINDOW, LAYOUT, VEC, uint64_t>(a, m, g * V, s, s2);
     }
     block_sum2<kBlock>(s, s2);
     if (threadIdx.x == 0) {
@@ -154,7 +173,8 @@ static hipError_t launch_store_t(const PathJob &j, int layout, void *d_traj, int
     a.counts = d_counts;
     a.payoffs = static_cast<T *>(d_payoffs);
     a.vec_ok = (j.n_local % V == 0) && (reinterpret_cast<uintptr_t>(d_traj) % 16 == 0) &&
-               (d_counts == nullptr || reinterpret_cast<uintptr_t>(d_counts) % 16 == 0);
+               (d_counts == nullptr || reinterpret_cast<uintptr_t>(d_counts) % 16 == 0) &&
+               (d_payoffs == nullptr || reinterpret_cast<uintptr_t>(d_payoffs) % 16 == 0);
     const dim3 g(grid), b(kBlock);
 #define MCAMD_LAUNCH_STORE(W, L, VEC) \
     hipLaunchKernelGGL((store_kernel<T, W, L, VEC>), g, b, 0, stream, a, d_partials)

@@ -256,6 +256,12 @@ def test_group_single_process_rccl_route(ctx):
             assert got.kernel_ms > 0
         empty = g.price_paths(opt, capi.make_sim(10, 3, capi.F64, n_paths_local=0))
         assert empty.n == 0 and empty.sum == 0
+        # a failed call (bad precision -> the enqueue is refused) drains the group and leaves it usable: the next
+        # call prices correctly, i.e. no RCCL group was left open and nothing was left running
+        with pytest.raises(capi.McamdError, match="precision"):
+            g.price_paths(opt, capi.make_sim(1000, 5, 16))
+        again = g.price_paths(opt, capi.make_sim(1_000_003, 12, capi.F64, seed=21))
+        assert math.isclose(again.sum, ctx.price_paths(opt, capi.make_sim(1_000_003, 12, capi.F64, seed=21)).sum, rel_tol=1e-12)
 
 
 def test_price_paths_empty_shard_and_errors(ctx):
@@ -666,6 +672,8 @@ def test_full_size_config4_reference_bullet_window(ctx, oracle):
     assert torch.allclose(out_w, out_b, rtol=1e-12, atol=1e-12) and math.isclose(rw.sum, rb.sum, rel_tol=1e-11)
     traj_f, cnt_f, out_f = dev(n_paths * n_steps, torch.float64), dev(n_paths * n_steps, torch.int32), dev(n_paths * n_steps, torch.float64)
     rf = ctx.nmc_fused(opt, inner, 1234, traj_f, cnt_f, out_f)
+    with pytest.raises(capi.McamdError, match="outer_seed"):      # equal seeds would alias the outer and inner streams
+        ctx.nmc_fused(opt, inner, 1235, traj_f, cnt_f, out_f)
     assert torch.equal(traj_f, traj) and torch.equal(cnt_f, cnt)
     assert torch.equal(out_f, out_w) and math.isclose(rf.sum, rw.sum, rel_tol=1e-11)
     V, S, C = out_w.view(n_steps, n_paths), traj.view(n_steps, n_paths), cnt.view(n_steps, n_paths)

@@ -59,6 +59,8 @@ def _compile(src: str, force: bool, extra) -> str:
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [
         os.path.join(ROOT, "include", "mcamd.h"), os.path.abspath(__file__)]
+    if src == "capi.cpp":   # carries the build id, a hash over EVERY source
+        deps += [os.path.join(CSRC, s_) for s_ in SOURCES]
     if force or _stale(obj, deps):
         cmd = [hipcc(), *_flags(extra), "-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):

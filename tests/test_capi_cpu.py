@@ -32,6 +32,17 @@ def test_exports_every_declared_symbol(lib):
     assert lib.mcamd_abi_version() == 3
 
 
+def test_slot_counts_describe_the_built_library(lib):
+    # bench.py prices the VALU roofline with ISA slot counts (profiles/valu_slots.json); they carry the id of the
+    # sources they were counted from, and build() refreshes them: library, sources and counts must agree
+    import json
+    bmod = importlib.import_module("monte-carlo-project-cuda_amd.build")
+    with open(os.path.join(ROOT, "profiles", "valu_slots.json")) as f:
+        counts = json.load(f)
+    assert capi.build_id() == bmod.build_id() == counts["build_id"]
+    assert 50 < counts["price_f64"] < 120 and 20 < counts["price_f32"] < 40
+
+
 def test_struct_layout_is_the_documented_abi():
     assert C.sizeof(capi.Option) == 88 and C.sizeof(capi.Sim) == 48
     assert C.sizeof(capi.Result) == 120 and C.sizeof(capi.DeviceInfo) == 384

@@ -220,6 +220,16 @@ def valu_roofline(W, stale, key, kernel, lane_steps_per_s, traffic_key=None, ext
           "path_steps_per_s_kernel": lane_steps_per_s, "valu_slots_per_path_step": w,
           "achieved": lane_steps_per_s * w / 1e12 if w else None,
           "frac": lane_steps_per_s * w / 1e12 / PEAK_VALU_TLANEOPS if w else None}
+    det = W.get(key + "_detail")
+    if w and det and det.get("measured_cost_cycles_per_iteration"):
+        # the same instruction count priced with the per-instruction issue costs MEASURED on MI355X
+        # (tools/ubench_valu.hip -> profiles/r01_valu_issue_costs.json; e.g. v_fma_f64 4.23 cycles, not 4): the
+        # fraction of the issue rate the hardware actually sustains for this instruction mix
+        ratio = det["measured_cost_cycles_per_iteration"] / det["issue_cycles_per_iteration"]
+        rl["issue_model"] = {"nominal_cycles_per_iteration": det["issue_cycles_per_iteration"],
+                             "measured_cost_cycles_per_iteration": det["measured_cost_cycles_per_iteration"],
+                             "path_steps_per_iteration": det["path_steps_per_iteration"],
+                             "frac_of_measured_issue_rate": rl["frac"] * ratio}
     if stale:
         rl["stale"] = stale
     if extra:

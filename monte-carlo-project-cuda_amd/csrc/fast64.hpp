@@ -117,6 +117,9 @@ MC_HD double fma_usv(double a, double k, double c) { return __builtin_fma(a, k, 
 MC_HD double fma_vvs(double a, double b, double k) { return __builtin_fma(a, b, k); }
 MC_HD double fma_vvv(double a, double b, double c) { return __builtin_fma(a, b, c); }
 #endif
+// a * k1 + k2 with two compile-time constants: left to the compiler (one of them lands in registers)
+MC_HD double fma_vss(double a, double k1, double k2) { return __builtin_fma(a, k1, k2); }
+
 // Hides a value's provenance from the optimiser (no instruction).  Used where ROCm 7.2's instruction selection
 // otherwise rewrites "(lo32(M * c) >> 11) & 0xfff" on a Philox output word into a second 32-bit multiply.
 MC_HD uint32_t opaque(uint32_t x)
@@ -136,8 +139,10 @@ MC_HD double u53(uint32_t x, uint32_t y, double c)
 {
     const uint32_t lo = x ^ (y << 21);
     const uint32_t hi = y >> 11;
-    const double v = __builtin_fma(static_cast<double>(hi), 0x1p32, static_cast<double>(lo));
-    return fma_us(v, c);
+    // (lo + 1) c without a conversion: lo sits in the mantissa of 2^52, and fma(2^52 + lo, c, c - 2^52 c) is exact
+    const double l = fma_usv(make_double(lo, 0x43300000u), c, c - 0x1p52 * c);
+    // + hi 2^32 c: exact too, the sum is (v + 1) c with v + 1 <= 2^53
+    return __builtin_fma(static_cast<double>(hi), 0x1p32 * c, l);
 }
 
 #include "tables64_consts.inc"
@@ -241,8 +246,9 @@ struct ExpAcc {
 MC_HD ExpAcc exp_acc_init() { return ExpAcc{1.0, 0}; }
 
 // multiplies the running product by e^x, given y = x * kExpScale.  c1 = kExpC1, passed in so that a kernel
-// can keep it in vector registers across its step loop (exp_c1_resident).
-MC_HD void exp_acc_mul(ExpAcc &a, double y, double c1 = kExpC1)
+// can keep it in vector registers across its step loop (exp_c1_resident).  Returns rint(y) as a double (what was
+// added to k), for callers that also track the exponent in floating point (the barrier test of mc_device.hpp).
+MC_HD double exp_acc_mul(ExpAcc &a, double y, double c1 = kExpC1)
 {
     // round-to-nearest by adding 1.5 * 2^52: the integer lands in the low mantissa word (|y| < 2^31)
     const double ks = y + 0x1.8p52;
@@ -251,6 +257,19 @@ MC_HD void exp_acc_mul(ExpAcc &a, double y, double c1 = kExpC1)
     a.k += static_cast<int32_t>(lo32(ks));
     const double t = rr * fma_usv(rr, kExpC2, c1);
     a.P = __builtin_fma(a.P, t, a.P);
+    return kd;
+}
+
+// Largest |ln P - (P - 1)| * kExpScale a path of n factors can reach: every factor is 1 + t with
+// |t| <= (1/2) kExpC1 (1 + 1e-5), so |ln P| <= L = n * 5.295e-6 and |ln P - (P - 1)| <= 0.55 (e^L - 1)^2 for L <= 0.3.
+// Used as the half-width of the band in which the cheap barrier test hands over to the exact one; +inf (always
+// exact) for paths too long for the bound.
+inline double exp_acc_window_delta(uint32_t n_factors)
+{
+    const double L = static_cast<double>(n_factors) * 5.295e-6;
+    if (!(L <= 0.3)) return __builtin_huge_val();
+    const double e = __builtin_expm1(L);
+    return 0.55 * e * e * kExpScale + 1e-6;
 }
 
 // kExpC1 in vector registers, opaque to rematerialisation: without this hipcc (ROCm 7.2) re-creates the constant

@@ -162,6 +162,7 @@ struct StepConsts {
     T B;        // barrier
     T S_start;  // S0, or Sk when restarting
     T logB;     // ln(B / S_start) in exponent units, -inf when B <= 0: barrier test in log space
+    T win_delta;  // fp64: half-width (exponent units) of the band where the cheap barrier test defers to the exact one
     int32_t P1, P2, Ik;
     uint32_t n_sim;  // steps to simulate = n_steps - Tk
 };
@@ -177,17 +178,40 @@ struct PathState<float> {
     __device__ __forceinline__ static PathState start(float S) { return PathState{S}; }
     __device__ __forceinline__ void step(float x, const MathCtx<float> &) { St *= __builtin_amdgcn_exp2f(x); }
     __device__ __forceinline__ float value(const MathCtx<float> &) const { return St; }
+    // barrier test B > St (inc/trajectories.cuh:147): the price is at hand
+    __device__ __forceinline__ void arm_barrier(float) {}
+    __device__ __forceinline__ bool below_barrier(const StepConsts<float> &c, const MathCtx<float> &) const { return c.B > St; }
 };
 
 template <>
 struct PathState<double> {
     double S0;
     f64::ExpAcc a;
-    __device__ __forceinline__ static PathState start(double S) { return PathState{S, f64::exp_acc_init()}; }
-    __device__ __forceinline__ void step(double y, const MathCtx<double> &m) { f64::exp_acc_mul(a, y, m.exp_c1); }
+    double kq;  // k - theta - kExpScale as a double, theta = log2(B / S0) * 65536 (set by arm_barrier; unused otherwise)
+    __device__ __forceinline__ static PathState start(double S) { return PathState{S, f64::exp_acc_init(), 0.0}; }
+    __device__ __forceinline__ void step(double y, const MathCtx<double> &m) { kq += f64::exp_acc_mul(a, y, m.exp_c1); }
     __device__ __forceinline__ double value(const MathCtx<double> &m) const
     {
         return f64::exp_acc_value(S0, a, m.t.exp_hi_tab, m.t.exp_lo_tab);
+    }
+    // Barrier test B > St without evaluating St.  In exponent units log2(St / B) * 65536 = k - theta + kExpScale ln P,
+    // and ln P = (P - 1) up to c.win_delta (P stays within 1 +- n * 5.3e-6: f64::exp_acc_window_delta), so
+    // q = fma(P, kExpScale, kq) decides unless |q| <= win_delta; then — for the whole wavefront, a few times per
+    // ten thousand steps — the price is evaluated and compared exactly as the trajectory-store kernel does, so both
+    // count the same steps.  theta: ln(B / S0) in exponent units (c.logB when the path starts at c.S_start).
+    __device__ __forceinline__ void arm_barrier(double theta) { kq = -theta - f64::kExpScale; }
+    __device__ __forceinline__ bool below_barrier(const StepConsts<double> &c, const MathCtx<double> &m) const
+    {
+        const double q = __builtin_fma(a.P, f64::kExpScale, kq);
+        const bool unsure = !(__builtin_fabs(q) > c.win_delta);   // also true for a NaN
+        if (__builtin_amdgcn_ballot_w64(unsure) != 0) {
+            // marker for tools/count_valu_slots.py: the basic block holding it runs for a few wavefront-steps in ten
+            // thousand and is left out of the static per-step instruction count (the PMC count in profiles/ is the
+            // dynamic check)
+            asm volatile("; MCAMD_RARE_BLOCK");
+            return c.B > value(m);
+        }
+        return q < 0.0;
     }
 };
 
@@ -273,8 +297,8 @@ __device__ __forceinline__ double exp_of_logreturn(double S, double y, const Mat
 // loop (checked once per Philox block: one compare and a scalar branch).  The reference tests this only before
 // the loop (inc/nmc.cuh:53, :330); the result is the same, the work is not: with the benchmark's bullet window
 // (B = 120, P2 = 50 of 252 steps, hello.cu:11-13) a continuation path is over after ~50 steps.
-// log_start: ln(St / c.S_start) in the exponent's units (0 when the path starts at c.S_start); only read
-// in LOGSPACE + WINDOW mode, where the barrier level is held as ln(B / c.S_start).
+// log_start: ln(St / c.S_start) in the exponent's units (0 when the path starts at c.S_start); read in WINDOW
+// mode by the log-space loop and by the fp64 barrier test, which hold the barrier level as ln(B / c.S_start).
 __device__ __forceinline__ float log_ratio(float a, float b) { return __builtin_amdgcn_logf(a / b); }  // log2
 __device__ __forceinline__ double log_ratio(double a, double b) { return log(a / b) * f64::kExpScale; }
 
@@ -346,13 +370,15 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
         // The barrier count needs St at every step (value()); a European path only at the end.
         Exponents<T> ex;
         const T two_drift = c.drift + c.drift;
-        PathState<T> ps = PathState<T>::start(St), ps2 = ps;
+        PathState<T> ps = PathState<T>::start(St);
+        if (WINDOW) ps.arm_barrier(c.logB - log_start);   // ln(B / St) = ln(B / S_start) - ln(St / S_start)
+        PathState<T> ps2 = ps;
         auto step = [&](T x) {
             ps.step(x, m);
-            if (WINDOW) count += (c.B > ps.value(m)) ? 1 : 0;
+            if (WINDOW) count += ps.below_barrier(c, m) ? 1 : 0;
             if (ANTI) {
                 ps2.step(two_drift - x, m);
-                if (WINDOW) count2 += (c.B > ps2.value(m)) ? 1 : 0;
+                if (WINDOW) count2 += ps2.below_barrier(c, m) ? 1 : 0;
             }
         };
         for (uint32_t k = 0; k < n_full; ++k) {

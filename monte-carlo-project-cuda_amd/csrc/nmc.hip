@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
             double acc = 0.0;
             uint32_t steps_run = 0;
             if (!WINDOW || cnt0 <= a.c.P2) {
-                const T ls = (WINDOW && LOGSPACE) ? log_ratio(St0, a.c.S_start) : T(0);
+                const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, a.c.S_start) : T(0);
                 for (uint32_t j = lane; j < a.n_inner; j += kWave)
                     acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(
                         a.c, m, a.seed, point_id * a.n_inner + j, St0, cnt0, remaining, ls, &steps_run));
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
         double acc = 0.0, work = 0.0;
         uint32_t steps_run = 0;
         if (!WINDOW || cnt0 <= a.c.P2) {
-            const T ls = (WINDOW && LOGSPACE) ? log_ratio(St0, a.c.S_start) : T(0);
+            const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, a.c.S_start) : T(0);
             for (uint32_t j = threadIdx.x; j < a.n_inner; j += kBlock)
                 acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(a.c, m, a.seed, point_id * a.n_inner + j,
                                                                                St0, cnt0, remaining, ls, &steps_run));
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
         double acc = 0.0;
         uint32_t steps_run = 0;
         if (!WINDOW || cnt0 <= c.P2) {
-            const T ls = (WINDOW && LOGSPACE) ? log_ratio(St0, c.S_start) : T(0);
+            const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
             for (uint32_t j = lane; j < a.n_inner; j += kWave)
                 acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, a.seed, point_id * a.n_inner + j, St0,
                                                                                cnt0, remaining, ls, &steps_run));

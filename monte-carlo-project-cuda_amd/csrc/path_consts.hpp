@@ -24,6 +24,7 @@ inline StepConsts<T> make_consts(const PathJob &j)
     c.S_start = static_cast<T>(j.S_start);
     c.logB = (j.B > 0.0 && j.S_start > 0.0) ? static_cast<T>(std::log(j.B / j.S_start) * scale)
                                              : -std::numeric_limits<T>::infinity();
+    c.win_delta = sizeof(T) == 8 ? static_cast<T>(f64::exp_acc_window_delta(j.n_steps)) : T(0);
     c.P1 = j.P1;
     c.P2 = j.P2;
     c.Ik = j.Ik;

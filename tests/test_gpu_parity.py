@@ -695,6 +695,24 @@ def test_full_size_config4_reference_bullet_window(ctx, oracle):
     assert abs(V[0].mean().item() - direct.price) < 5 * (direct.std_err + 10.0 / math.sqrt(n_paths * n_inner) + 8.0 / math.sqrt(n_paths))
 
 
+def test_accuracy_252_variance_reduced_estimator_scales_to_1e_minus_4(ctx):
+    # north-star "price within 1e-4 of closed form" on the 252-step BASELINE shape: antithetic pairs + S_T control
+    # variate, fp64.  At 1e7 and 1e8 samples the standard error must fall as 1/sqrt(n) (so that bench.py's 1e9 samples
+    # give 4.6e-5) and the price must sit within 4 SE of the closed form at both sizes.
+    fl = capi.FLAG_ANTITHETIC | capi.FLAG_CONTROL_VARIATE
+    opt = capi.make_option(**BENCH)
+    small = ctx.price_paths(opt, capi.make_sim(10_000_000, 252, capi.F64, seed=20260101, flags=fl))
+    big = ctx.price_paths(opt, capi.make_sim(100_000_000, 252, capi.F64, seed=20260101, flags=fl))
+    for r in (small, big):
+        assert abs(r.price - BS) <= 4 * r.std_err, (r.price, r.std_err)
+        assert 0.97 < r.cv_rho < 0.985
+    assert math.isclose(big.std_err, small.std_err / math.sqrt(10), rel_tol=0.02)
+    assert math.isclose(big.std_err, 4.55e-4 / math.sqrt(10), rel_tol=0.03)      # -> 4.55e-5 at 1e9 samples
+    assert big.std_err / math.sqrt(10) < 5e-5                                       # 1e9 samples resolve 1e-4 at 2 SE
+    plain_se = 16.109 * math.exp(-0.1) / math.sqrt(100_000_000)
+    assert (plain_se / big.std_err) ** 2 > 90                                        # variance cut per sample
+
+
 def test_full_size_config5_rank_shard_properties(ctx):
     # config 5: 1B paths x 252 steps, fp64, path-sharded over 8 GPUs.  One GPU here: simulate what rank 3 of 8 does
     # (global ids [375M, 500M)) and check that (1) the shard splits exactly into two sub-shards (any sharding of the

@@ -44,6 +44,34 @@ def cycles(op: str) -> int:
     return 2
 
 
+def measured_costs():
+    """Issue cost per instruction as MEASURED on MI355X by tools/ubench_valu.hip (profiles/r01_valu_issue_costs.json:
+    cycles per wave64 instruction per SIMD, 8 waves per SIMD).  Instructions the microbenchmark did not cover fall
+    back to the class weight of cycles()."""
+    path = os.path.join(ROOT, "profiles", "r01_valu_issue_costs.json")
+    table = {}
+    try:
+        with open(path) as f:
+            for row in json.load(f)["rows"]:
+                table[row["inst"].split("(")[0]] = row["cycles_per_wave_inst_per_simd"]
+    except (OSError, ValueError, KeyError):
+        return None
+    alias = {"v_fmac_f64": "v_fma_f64", "v_fmac_f32": "v_fma_f32", "v_fmamk_f32": "v_fma_f32", "v_fmaak_f32": "v_fma_f32",
+             "v_sub_u32": "v_add_u32", "v_and_b32": "v_xor_b32", "v_or_b32": "v_xor_b32", "v_mov_b32": "v_xor_b32",
+             "v_lshrrev_b32": "v_lshlrev_b32", "v_ashrrev_i32": "v_lshlrev_b32", "v_bfe_u32": "v_lshlrev_b32",
+             "v_cvt_f64_u32": "v_cvt_f32_u32", "v_cvt_f64_i32": "v_cvt_f32_u32", "v_cvt_i32_f64": "v_cvt_f32_u32",
+             "v_pk_mul_f32": "v_pk_fma_f32", "v_cmp_le_i32": "v_cmp_gt_f32", "v_cmp_gt_f64": "v_cmp_gt_f64",
+             "v_sin_f32": "v_sin_f32", "v_cos_f32": "v_cos_f32"}
+
+    def cost(op: str) -> float:
+        base = re.sub(r"_e(32|64)$", "", op)
+        base = alias.get(base, base)
+        if base in table:
+            return table[base]
+        return float(cycles(op))
+    return cost
+
+
 def asm_of(src: str) -> str:
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
@@ -64,8 +92,17 @@ def step_loop(asm: str, symbol: str):
     for i, l in enumerate(lines):
         mm = re.match(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l) or re.match(r"s_branch (\.LBB\d+_\d+)", l)
         if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
-            ins = [x.split()[0] for x in lines[labels[mm.group(1)]:i + 1]
-                   if x and not x.startswith((".", ";")) and not x.endswith(":")]
+            # basic blocks the source marks as rare (mc_device.hpp below_barrier: the exact barrier test, taken by a
+            # wavefront a few times per ten thousand steps) are not part of the per-step count.  A block runs from a
+            # label or a "; %bb.N:" comment to the next one.
+            seg = lines[labels[mm.group(1)]:i + 1]
+            starts = [k for k, x in enumerate(seg) if re.match(r"^\.LBB\d+_\d+:", x) or x.startswith("; %bb.")] + [len(seg)]
+            body = []
+            for b0, b1 in zip(starts[:-1], starts[1:]):
+                blk = seg[b0:b1]
+                if not any("MCAMD_RARE_BLOCK" in x for x in blk):
+                    body.extend(blk)
+            ins = [x.split()[0] for x in body if x and not x.startswith((".", ";")) and not x.endswith(":")]
             # the step loop carries a whole Philox4x32-10 (20 32x32->64 multiplies, a few hoisted): other loops of a
             # kernel may hold a stray multiply (64-bit index arithmetic) and must not be mistaken for it
             if ins.count("v_mad_u64_u32") + ins.count("v_mul_hi_u32") >= 12:
@@ -90,6 +127,7 @@ KERNELS = {
 def main():
     cache, result, md = {}, {}, ["# VALU issue slots per path-step (gfx950 ISA of the shipped inner loops)\n",
                                  "Generated by tools/count_valu_slots.py; weights from profiles/r01_valu_issue_costs.json.\n"]
+    cost = measured_costs()
     for key, (src, sym, steps) in KERNELS.items():
         asm = cache.setdefault(src, asm_of(src))
         ins = step_loop(asm, sym)
@@ -100,9 +138,14 @@ def main():
         result[key] = round(slots, 2)
         result[key + "_detail"] = {"loop_instructions": len(ins), "valu_instructions": valu, "issue_cycles_per_iteration": cyc,
                                    "path_steps_per_iteration": steps}
+        if cost is not None:   # the same count priced with the per-instruction costs measured on the chip
+            result[key + "_detail"]["measured_cost_cycles_per_iteration"] = round(
+                sum(cost(op) * n for op, n in cnt.items() if op.startswith("v_")), 1)
         md.append(f"\n## {key}: `{sym}`\n")
         md.append(f"{len(ins)} instructions per loop iteration ({valu} VALU), {steps} path-steps per iteration, "
-                  f"{cyc} issue cycles -> **{slots:.1f} slots per path-step**\n")
+                  f"{cyc} issue cycles -> **{slots:.1f} slots per path-step**"
+                  + (f" (priced with the issue costs measured on MI355X, r01_valu_issue_costs.json: "
+                     f"{result[key + '_detail']['measured_cost_cycles_per_iteration']} cycles per iteration)" if cost else "") + "\n")
         md.append("| count | instruction | cycles each |\n|---:|---|---:|")
         for op, n in sorted(cnt.items(), key=lambda kv: (-cycles(kv[0]) * kv[1], kv[0])):
             md.append(f"| {n} | `{op}` | {cycles(op)} |")

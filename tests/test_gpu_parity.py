@@ -653,6 +653,23 @@ def test_closed_window_early_exit_changes_nothing(ctx, oracle, prec, flags):
     assert res.sum > 0
 
 
+@pytest.mark.parametrize("n_paths,n_steps", [(3000, 5001), (300, 60_000)])
+def test_barrier_test_band_scales_with_path_length(ctx, oracle, n_paths, n_steps):
+    # the fp64 barrier test decides from the factored price (k, P) and falls back to the exact comparison inside a
+    # band whose width grows with the path length (f64::exp_acc_window_delta): 5001 steps use a wide band, 60 000
+    # steps are beyond the bound and take the exact test at every step.  Counts must match the oracle's either way.
+    opt = capi.make_option(**BENCH, B=104.0, P1=n_steps // 4, P2=(3 * n_steps) // 4, use_window=1)
+    sim = capi.make_sim(n_paths, n_steps, capi.F64, seed=31)
+    res = ctx.price_paths(opt, sim)
+    ref = oracle.mc_paths(oparams(oracle, opt, sim), capi.F64, 0, n_paths, threads=oracle.max_threads())
+    assert math.isclose(res.sum, ref["sum"], rel_tol=1e-10) and res.sum > 0
+    traj, cnt = dev(n_paths * n_steps, torch.float64), dev(n_paths * n_steps, torch.int32)
+    pay = dev(n_paths, torch.float64)
+    st = ctx.simulate_trajectories(opt, sim, traj, cnt, pay)
+    # the store kernel compares the evaluated price at every step: same counts, same payoffs (sums differ by order only)
+    assert math.isclose(st.sum, res.sum, rel_tol=1e-13)
+
+
 def test_full_size_config4_reference_bullet_window(ctx, oracle):
     # config 4 as hello.cu runs it: nested MC, 65 536 outer x 252 steps x 1000 inner, fp64, bullet window B = 120,
     # P1 = 10, P2 = 50 (hello.cu:11-15).  Checks: (1) a sample of points against oracle_nmc_point (1e-11);

@@ -82,16 +82,9 @@ MC_HD double rsq_seed(double a)
 // v_fmac_f64 and has to copy a loop-invariant addend into a fresh accumulator first (a v_mov_b64, or two
 // v_mov_b32 from SGPRs, per use: ~6 % of the fp64 step loop).  One VALU instruction each, register operands
 // only; their inputs never come straight from a transcendental op, so no wait state is owed inside.
-//   fma_us(a, k)      a * k + k         k wave-uniform (SGPR pair used twice)
 //   fma_usv(a, k, c)  a * k + c         k wave-uniform, c a value kept in VGPRs (loop-invariant constant)
 //   fma_vvs(a, b, k)  a * b + k         k wave-uniform
 #if defined(__HIP_DEVICE_COMPILE__)
-MC_HD double fma_us(double a, double k)
-{
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %2" : "=v"(d) : "v"(a), "s"(k));
-    return d;
-}
 MC_HD double fma_usv(double a, double k, double c)
 {
     double d;
@@ -112,14 +105,10 @@ MC_HD double fma_vvv(double a, double b, double c)
     return d;
 }
 #else
-MC_HD double fma_us(double a, double k) { return __builtin_fma(a, k, k); }
 MC_HD double fma_usv(double a, double k, double c) { return __builtin_fma(a, k, c); }
 MC_HD double fma_vvs(double a, double b, double k) { return __builtin_fma(a, b, k); }
 MC_HD double fma_vvv(double a, double b, double c) { return __builtin_fma(a, b, c); }
 #endif
-// a * k1 + k2 with two compile-time constants: left to the compiler (one of them lands in registers)
-MC_HD double fma_vss(double a, double k1, double k2) { return __builtin_fma(a, k1, k2); }
-
 // Hides a value's provenance from the optimiser (no instruction).  Used where ROCm 7.2's instruction selection
 // otherwise rewrites "(lo32(M * c) >> 11) & 0xfff" on a Philox output word into a second 32-bit multiply.
 MC_HD uint32_t opaque(uint32_t x)

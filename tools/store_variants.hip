@@ -7,6 +7,7 @@
 //   tools/store_variants [paths=100000000] [steps=252]     -> one JSON line per variant
 #include "path_consts.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -27,13 +28,18 @@ using f4 = float __attribute__((ext_vector_type(4)));
 // G 16-byte groups per thread; group g of a thread sits G_STRIDE lanes-groups away so every store instruction of a
 // wave still writes 1 KiB contiguous.  NT: non-temporal hint.  PRIO: raise the wave's priority around the stores.
 // MINW: __launch_bounds__ minimum waves per SIMD (register budget).
-template <int G, bool NT, int PRIO, int MINW>
+// EVERY: store one row in EVERY (1 = all rows; 2 = half the bytes with the same arithmetic; 0 = no trajectory stores):
+// separates "the arithmetic is slow" from "the arithmetic is slow WHILE the memory system is busy".
+template <int G, bool NT, int PRIO, int MINW, int EVERY = 1>
 __global__ __launch_bounds__(kBlock, MINW) void variant_kernel(StepConsts<float> c, uint64_t seed, uint64_t n_local,
                                                                float *__restrict__ traj, float *__restrict__ payoffs,
-                                                               double *__restrict__ partials)
+                                                               double *__restrict__ partials,
+                                                               uint64_t *__restrict__ stamps)
 {
     constexpr int V = 4, NB = 4;
     const MathCtx<float> m = MathCtx<float>::init();
+    // diagnostic stamps (this harness only): shader cycles and 100 MHz ticks around the wave's whole life
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
     const uint64_t n_groups = n_local / V;                       // n_local % (V * G * 64) == 0 assumed by the harness
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock * G;
     const uint32_t n_full = c.n_sim / NB;
@@ -65,6 +71,7 @@ __global__ __launch_bounds__(kBlock, MINW) void variant_kernel(StepConsts<float>
                         pack[g][p] = St[g][p];
                     }
                 const uint64_t row = static_cast<uint64_t>(k * NB + j) * n_local;
+                if (EVERY == 0 || (EVERY > 1 && (j % EVERY) != 0)) continue;
                 if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -88,10 +95,18 @@ __global__ __launch_bounds__(kBlock, MINW) void variant_kernel(StepConsts<float>
             if (payoffs) *reinterpret_cast<f4 *>(payoffs + base[g]) = pay;
         }
     }
+    const uint32_t done = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(__double2hiint(s)));
+    asm volatile("" ::"s"(done));
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
     block_sum2<kBlock>(s, s2);
     if (threadIdx.x == 0) {
         partials[2 * blockIdx.x] = s;
         partials[2 * blockIdx.x + 1] = s2;
+    }
+    if (stamps && lane == 0 && blockIdx.x % 16 == 0) {   // a sample of the waves is enough for a median
+        const uint64_t w = (static_cast<uint64_t>(blockIdx.x) / 16) * (kBlock / 64) + threadIdx.x / 64;
+        stamps[2 * w] = t1 - t0;
+        stamps[2 * w + 1] = w1 - w0;
     }
 }
 
@@ -168,6 +183,19 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&t.e0));
     CK(hipEventCreate(&t.e1));
     const double bytes = static_cast<double>(n_paths) * n_steps * 4.0 + static_cast<double>(n_paths) * 4.0;
+    uint64_t *stamps = nullptr;
+    const size_t n_stamp_waves = (static_cast<size_t>(grid1) / 16 + 1) * (kBlock / 64);
+    CK(hipMalloc(&stamps, 2 * sizeof(uint64_t) * n_stamp_waves));
+    auto clock_ghz = [&](uint32_t grid) {   // median in-kernel clock of the last launch: d(memtime) / d(memrealtime) x 100 MHz
+        const size_t n = (static_cast<size_t>(grid) / 16) * (kBlock / 64);
+        std::vector<uint64_t> h(2 * n);
+        if (n == 0) return 0.0;
+        (void)hipMemcpy(h.data(), stamps, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+        std::vector<double> g(n);
+        for (size_t i = 0; i < n; ++i) g[i] = h[2 * i + 1] ? 0.1 * static_cast<double>(h[2 * i]) / static_cast<double>(h[2 * i + 1]) : 0.0;
+        std::sort(g.begin(), g.end());
+        return g[n / 2];
+    };
     auto price = [&](uint32_t grid) {
         std::vector<double> h(2 * grid);
         (void)hipMemcpy(h.data(), part, h.size() * sizeof(double), hipMemcpyDeviceToHost);
@@ -175,16 +203,18 @@ int main(int argc, char **argv)
         for (uint32_t b = 0; b < grid; ++b) s += h[2 * b];
         return std::exp(-0.1) * s / static_cast<double>(n_paths);
     };
-#define RUN(NAME, G, NT, PRIO, MINW, GRID)                                                                              \
+#define RUN_E(NAME, G, NT, PRIO, MINW, GRID, EVERY, BYTES)                                                              \
     do {                                                                                                                \
         const uint32_t grid_ = (GRID);                                                                                  \
         double dummy;                                                                                                   \
-        if (time_it(NAME, bytes, t, [&] {                                                                               \
-                hipLaunchKernelGGL((variant_kernel<G, NT, PRIO, MINW>), dim3(grid_), dim3(kBlock), 0, 0, c, 1234ull,     \
-                                   n_paths, traj, pay, part);                                                           \
+        if (time_it(NAME, BYTES, t, [&] {                                                                               \
+                hipLaunchKernelGGL((variant_kernel<G, NT, PRIO, MINW, EVERY>), dim3(grid_), dim3(kBlock), 0, 0, c,       \
+                                   1234ull, n_paths, traj, pay, part, stamps);                                          \
             }, &dummy)) return 1;                                                                                       \
-        std::printf(", \"grid\": %u, \"price\": %.6f}\n", grid_, price(grid_));                                         \
+        std::printf(", \"grid\": %u, \"price\": %.6f, \"in_kernel_clock_ghz\": %.3f}\n", grid_, price(grid_),         \
+                    clock_ghz(grid_));                                                                                  \
     } while (0)
+#define RUN(NAME, G, NT, PRIO, MINW, GRID) RUN_E(NAME, G, NT, PRIO, MINW, GRID, 1, bytes)
     const uint32_t full1 = static_cast<uint32_t>(n_paths / 4 / kBlock);        // one 16-byte group per thread
     const uint32_t full2 = static_cast<uint32_t>(n_paths / 8 / kBlock);        // two groups per thread
     if (time_it("pure_stores_nt", bytes, t, [&] { hipLaunchKernelGGL(rows_kernel<true>, dim3(full1), dim3(kBlock), 0, 0, traj, n_paths, n_steps); })) return 1;
@@ -199,6 +229,10 @@ int main(int argc, char **argv)
     RUN("g2_nt_prio0_w1", 2, true, 0, 1, full2);
     RUN("g2_plain_prio0_w1", 2, false, 0, 1, full2);
     RUN("g2_plain_prio0_w4", 2, false, 0, 4, full2);
+    // coupling experiment: the same arithmetic with half / none of the rows stored
+    RUN_E("g1_nt_half_the_rows_stored", 1, true, 0, 1, full1, 2, bytes / 2);
+    RUN_E("g1_no_rows_stored", 1, true, 0, 1, full1, 0, static_cast<double>(n_paths) * 4.0);
+    RUN("g1_nt_prio0_w1 (again)", 1, true, 0, 1, full1);
     RUN("g1_nt_persistent_2048", 1, true, 0, 1, 2048);
     RUN("g1_plain_persistent_4096", 1, false, 0, 1, 4096);
     return 0;

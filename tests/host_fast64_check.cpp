@@ -27,7 +27,7 @@ int main(int argc, char **argv)
     const long n = argc > 1 ? std::atol(argv[1]) : 4000000;
     const Tables T{reinterpret_cast<const D2 *>(kLogTab), reinterpret_cast<const D2 *>(kSinCosTab), kExpHiTab, kExpLoTab};
     std::mt19937_64 gen(12345);
-    double e_log = 0, e_sqrt = 0, e_sin = 0, e_cos = 0, e_exp = 0, e_u = 0, e_prod = 0, e_wide = 0, e_sqs = 0;
+    double e_log = 0, e_sqrt = 0, e_sin = 0, e_cos = 0, e_exp = 0, e_u = 0, e_prod = 0, e_wide = 0, e_sqs = 0, e_band = 0;
     const long double PI = 3.14159265358979323846264338327950288L;
     for (long i = 0; i < n; ++i) {
         const uint64_t a = gen(), b = gen();
@@ -89,6 +89,12 @@ int main(int argc, char **argv)
                                       expl(sum * (0.693147180559945309417232121458176568L / 65536.0L));
             const double ep = ulp_err(gotp, wantp);
             if (ep > e_prod) e_prod = ep;
+            // the cheap barrier test of mc_device.hpp reads log2(product) * 65536 as k + (P - 1) kExpScale; its
+            // distance from the true value must stay inside the band exp_acc_window_delta() hands to the exact test
+            const long double true_units = sum;                                         // log2(prod) * 65536, exactly
+            const long double approx_units = static_cast<long double>(acc.k) + (static_cast<long double>(acc.P) - 1.0L) * kExpScale;
+            const double band = static_cast<double>(fabsl(approx_units - true_units)) / exp_acc_window_delta(252);
+            if (band > e_band) e_band = band;
         }
     }
     // saturation instead of wrap-around: a huge exponent gives inf / 0, never a finite wrong value
@@ -97,6 +103,6 @@ int main(int argc, char **argv)
         if (!std::isinf(big) || tiny != 0.0) e_exp = 1e30;
     }
     std::printf("{\"n\": %ld, \"uniform_mismatch\": %g, \"neg2log_ulp\": %.3f, \"sqrt_ulp\": %.3f, \"sin_abs\": %.3g, "
-                "\"cos_abs\": %.3g, \"mul_exp_ulp\": %.3f, \"product252_ulp\": %.3f, \"mul_exp_wide_ulp_per_unit_x\": %.3f, \"sqrt_scaled_ulp\": %.3f}\n", n, e_u, e_log, e_sqrt, e_sin, e_cos, e_exp, e_prod, e_wide, e_sqs);
+                "\"cos_abs\": %.3g, \"mul_exp_ulp\": %.3f, \"product252_ulp\": %.3f, \"mul_exp_wide_ulp_per_unit_x\": %.3f, \"sqrt_scaled_ulp\": %.3f, \"barrier_band_used\": %.4f}\n", n, e_u, e_log, e_sqrt, e_sin, e_cos, e_exp, e_prod, e_wide, e_sqs, e_band);
     return 0;
 }

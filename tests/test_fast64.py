@@ -21,6 +21,8 @@ def test_fast64_accuracy_against_long_double_libm(tmp_path):
     assert r["mul_exp_ulp"] <= 4.5                       # one factor S e^x, |x| <= 1: 2 table entries + 3 multiplies
     assert r["mul_exp_wide_ulp_per_unit_x"] <= 3.5       # |x| up to 300: the error grows with the exponent's own ulp
     assert r["product252_ulp"] <= 64.0                   # 252-factor recurrence: rounding random-walks as sqrt(n)
+    # cheap barrier test: |k + (P - 1) kappa - log2(prod) 65536| as a fraction of the band that defers to the exact test
+    assert 0.0 < r["barrier_band_used"] < 1.0
 
 
 def test_tables_are_reproducible_from_the_generator():

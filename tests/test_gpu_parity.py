@@ -576,6 +576,87 @@ def test_nmc_variants_agree_and_european_window(ctx):
     assert np.abs(got - bs).max() < 6 * 16.0 / math.sqrt(n_inner)
 
 
+def test_randomised_jobs_vs_oracle(ctx, oracle):
+    # differential fuzz: random option parameters, step counts (odd and even), barrier levels on both sides of the
+    # spot, windows that close early / never / at once, restart triples, both precisions, the opt-in modes.  Every
+    # job's payoff sum must equal the oracle's (fp64 1e-10; fp32 within the hardware-transcendental tolerance).
+    rng = np.random.default_rng(20260102)
+    n_fail = []
+    for case in range(60):
+        prec = capi.F64 if case % 3 else capi.F32
+        n_steps = int(rng.choice([1, 2, 3, 7, 12, 33, 100, 253, 400]))
+        n_paths = int(rng.integers(1, 6000))
+        S0 = float(rng.uniform(20, 200))
+        K = S0 * float(rng.uniform(0.7, 1.3))
+        T = float(rng.uniform(0.1, 3.0))
+        r = float(rng.uniform(-0.02, 0.15))
+        v = float(rng.choice([0.01, 0.05, 0.2, 0.45, 0.9]))
+        window = int(rng.integers(0, 2)) if n_steps > 1 else 0
+        B = S0 * float(rng.choice([0.0, 0.8, 0.97, 1.0, 1.03, 1.25, 5.0]))
+        P1 = int(rng.integers(0, n_steps + 1))
+        P2 = int(rng.integers(P1, n_steps + 2)) if rng.random() < 0.8 else int(rng.integers(0, P1 + 1))
+        Tk = int(rng.integers(0, n_steps)) if (window and rng.random() < 0.3) else 0
+        Ik = int(rng.integers(0, 5)) if Tk else 0
+        Sk = S0 * float(rng.uniform(0.8, 1.2)) if Tk else 0.0
+        flags = int(rng.choice([0, 0, 0, capi.FLAG_LOG_SPACE, capi.FLAG_ANTITHETIC]))
+        dt = float(T / n_steps * rng.uniform(0.5, 1.5)) if (n_steps > 1 and rng.random() < 0.2) else 0.0
+        opt = capi.make_option(S0, T, K, r, v, B=B, P1=P1, P2=P2, use_window=window, Ik=Ik, Sk=Sk, Tk=Tk, dt=dt)
+        sim = capi.make_sim(n_paths, n_steps, prec, seed=int(rng.integers(1, 1 << 40)),
+                            path_offset=int(rng.integers(0, 1 << 45)), n_paths_local=n_paths, flags=flags)
+        res = ctx.price_paths(opt, sim)
+        p = oparams(oracle, opt, sim)
+        p.dt = dt
+        if flags & capi.FLAG_ANTITHETIC:
+            want = oracle.mc_paths_vr(p, prec, sim.path_offset, n_paths, True, 0.0, threads=4)[0]
+        else:
+            want = oracle.mc_paths(p, prec, sim.path_offset, n_paths, threads=4)["sum"]
+        if prec == capi.F64:
+            ok = math.isclose(res.sum, want, rel_tol=1e-10 if not flags else 1e-8, abs_tol=1e-9)
+        else:
+            # fp32: hardware transcendentals; a path within rounding of the barrier or the strike may flip
+            ok = math.isclose(res.sum, want, rel_tol=5e-3, abs_tol=2e-3 * n_paths * max(1.0, v * math.sqrt(n_steps)))
+        if not ok:
+            n_fail.append((case, prec, n_steps, n_paths, window, B / S0, P1, P2, Tk, flags, res.sum, want))
+    assert not n_fail, n_fail[:5]
+
+
+def test_randomised_nested_mc_vs_oracle(ctx, oracle):
+    # differential fuzz of the nested-MC stage: random windows (closing early, never, already closed), inner counts
+    # around the wavefront width, both layouts, the three strategies; every point price against oracle_nmc_point
+    rng = np.random.default_rng(7)
+    for case in range(24):
+        prec = capi.F64 if case % 4 else capi.F32
+        n_paths, n_steps, n_inner = int(rng.integers(1, 9)), int(rng.integers(2, 24)), int(rng.choice([1, 5, 63, 64, 65, 130]))
+        B = 100.0 * float(rng.choice([0.0, 0.9, 1.0, 1.08, 3.0]))
+        P1 = int(rng.integers(0, n_steps))
+        P2 = int(rng.integers(P1, n_steps + 1))
+        layout = capi.STEP_MAJOR if case % 2 else capi.PATH_MAJOR
+        opt = capi.make_option(**BENCH, B=B, P1=P1, P2=P2, use_window=1)
+        so, si = int(rng.integers(1, 1 << 30)), int(rng.integers(1 << 30, 1 << 31))
+        outer = capi.make_sim(n_paths, n_steps, prec, seed=so)
+        inner = capi.make_sim(n_paths, n_steps, prec, seed=si, n_paths_inner=n_inner)
+        traj, cnt = dev(n_paths * n_steps, TORCH_T[prec]), dev(n_paths * n_steps, torch.int32)
+        outs = [dev(n_paths * n_steps, TORCH_T[prec]) for _ in range(3)]
+        ctx.simulate_trajectories(opt, outer, traj, cnt, None, layout)
+        ctx.nmc_inner(opt, inner, traj, cnt, outs[0], layout, capi.NMC_WAVE_PER_POINT)
+        ctx.nmc_inner(opt, inner, traj, cnt, outs[1], layout, capi.NMC_BLOCK_PER_POINT)
+        t2, c2 = torch.empty_like(traj), torch.empty_like(cnt)
+        ctx.nmc_fused(opt, inner, so, t2, c2, outs[2], layout)
+        assert torch.equal(t2, traj) and torch.equal(c2, cnt)
+        shape = (n_steps, n_paths) if layout == capi.STEP_MAJOR else (n_paths, n_steps)
+        T_, C_ = (a.cpu().numpy().reshape(shape) for a in (traj, cnt))
+        O_ = [o.cpu().numpy().reshape(shape) for o in outs]
+        if layout == capi.PATH_MAJOR:
+            T_, C_, O_ = T_.T, C_.T, [o.T for o in O_]
+        p = oparams(oracle, opt, inner)
+        want = np.array([[oracle.nmc_point(p, prec, q * n_steps + s_, s_, float(T_[s_, q]), int(C_[s_, q]))
+                          for q in range(n_paths)] for s_ in range(n_steps)])
+        rtol, atol = (1e-11, 1e-10) if prec == capi.F64 else (5e-3, 5e-3)
+        for o in O_:
+            assert np.allclose(o, want, rtol=rtol, atol=atol), (case, np.abs(o - want).max())
+        assert np.array_equal(O_[0], O_[2])          # fused == wave, bit for bit
+
+
 # ---------------- BASELINE.json full sizes: size-independent properties ----------------
 def test_full_size_config2_properties(ctx):
     # config 2: 10M paths x 252 steps, fp64, in-register.  Properties: price within 4 SE of closed form;

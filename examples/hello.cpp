@@ -28,6 +28,8 @@ int main()
     constexpr int kBlocks = 5000;            // likewise (hello.cu:38-40)
 
     printOptionData(od);
+    int n_devices = 0;
+    testCUDA(mcamd_device_count(&n_devices));   // the reference's error macro (inc/tool.cuh:92-100) on an engine status code
     getDeviceProperty();
 
     const std::array<SingleLevel, 5> single = {wrapper_cpu_option_vanilla, wrapper_cpu_bullet_option,

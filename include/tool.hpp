@@ -6,6 +6,7 @@
 //   simulateOptionPriceCPU         inc/tool.cuh:104-130 (serial CPU MC, one exact step)
 //   simulateBulletOptionPriceCPU   inc/tool.cuh:133-173 (serial CPU MC, N_STEPS steps + window)
 //   CHECK_MALLOC                   inc/tool.cuh:47-53
+//   testCUDA                       inc/tool.cuh:92-100  (takes an mcamd status code)
 //   get_max_blocks                 inc/tool.cuh:176-188
 //   isPow2 / nextPow2              inc/tool.cuh:200-210
 // setup_kernel (inc/tool.cuh:192-195) has no counterpart: the engine's Philox counters live in
@@ -50,6 +51,18 @@ static_assert(sizeof(OptionData) == 48, "OptionData must keep the reference's 48
         }                                                                                                  \
     } while (0)
 #endif
+
+// Caller-side status check with the reference's name and behaviour (inc/tool.cuh:92-100): message to stderr, then
+// exit.  It takes an mcamd status code (MCAMD_OK plays cudaSuccess).  Like CHECK_MALLOC it is the CALLING program's
+// policy: the engine itself never exits, it returns the code and keeps the text in mcamd_last_error().
+inline void testCUDA(int status, const char *file, int line)
+{
+    if (status != MCAMD_OK) {
+        std::cerr << "mcamd Error: " << mcamd_last_error() << " in file " << file << " at line " << line << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+}
+#define testCUDA(status) (testCUDA((status), __FILE__, __LINE__))
 
 namespace mcamd_shim {
 

@@ -170,12 +170,13 @@ MC_HD double sqrt_pos(double a)
     return __builtin_fma(d, h, g);
 }
 
-// k * sqrt(a), a >= 0, for the Box-Muller radius times the step volatility: hardware reciprocal-sqrt seed y
+// k * sqrt(a), a > 0, for the Box-Muller radius times the step volatility: hardware reciprocal-sqrt seed y
 // (relative error e0 <= 2^-22), e = 1 - a y^2, sqrt(a) = a y (1 - e)^(-1/2) = a y (1 + e/2 + 3 e^2/8 + O(e^3)):
 // one cubic step, six fp64 operations including the scaling (sqrt_pos + multiply: eight); <= 1.5 ulp.
+// No clamp: a = neg2log(u) is strictly positive for every u in (0, 1] (the table entry that serves u = 1 is biased
+// by 4e-18, tools/gen_tables64.py), so the seed is finite.
 MC_HD double sqrt_scaled(double a, double k)
 {
-    a = __builtin_fmax(a, 1e-300);
     const double y = rsq_seed(a);
     const double g = a * y;
     const double e = __builtin_fma(-y, g, 1.0);

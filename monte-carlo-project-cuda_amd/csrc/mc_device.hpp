@@ -31,8 +31,24 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
                                             uint32_t k1)
 {
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    // round 1 with plain xors, grouped so that the pair of inputs that is wave-uniform in every kernel here (the key
+    // word with the block counter's high word; the key word with the high product of the block counter's low word)
+    // is combined on the scalar unit: a three-input v_bitop3 would need two scalar operands, one more than a
+    // vector instruction may read, and cost a v_mov per block
+    {
+        const uint64_t p0 = static_cast<uint64_t>(M0) * c0;
+        const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
+        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ (c1 ^ k0);
+        const uint32_t n2 = c3 ^ (static_cast<uint32_t>(p0 >> 32) ^ k1);
+        c1 = static_cast<uint32_t>(p1);
+        c3 = static_cast<uint32_t>(p0);
+        c0 = n0;
+        c2 = n2;
+        k0 += W0;
+        k1 += W1;
+    }
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 1; i < 10; ++i) {
         const uint64_t p0 = static_cast<uint64_t>(M0) * c0;
         const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
         // three-input xor in one full-rate instruction (v_bitop3_b32, truth table 0x96)

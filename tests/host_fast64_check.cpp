@@ -27,7 +27,7 @@ int main(int argc, char **argv)
     const long n = argc > 1 ? std::atol(argv[1]) : 4000000;
     const Tables T{reinterpret_cast<const D2 *>(kLogTab), reinterpret_cast<const D2 *>(kSinCosTab), kExpHiTab, kExpLoTab};
     std::mt19937_64 gen(12345);
-    double e_log = 0, e_sqrt = 0, e_sin = 0, e_cos = 0, e_exp = 0, e_u = 0, e_prod = 0, e_wide = 0, e_sqs = 0, e_band = 0;
+    double e_log = 0, e_sqrt = 0, e_sin = 0, e_cos = 0, e_exp = 0, e_u = 0, e_prod = 0, e_wide = 0, e_sqs = 0, e_band = 0, e_pos = 0;
     const long double PI = 3.14159265358979323846264338327950288L;
     for (long i = 0; i < n; ++i) {
         const uint64_t a = gen(), b = gen();
@@ -42,6 +42,7 @@ int main(int argc, char **argv)
         const double u_ref = std::fma(static_cast<double>(v1), 0x1p-53, 0x1p-53);
         if (u != u_ref) e_u = 1;
         const double aa = neg2log(u, T.log_tab);
+        if (!(aa > 0.0)) e_pos = 1.0;   // the radius path divides by sqrt(aa): strictly positive for every u in (0, 1]
         const long double want_a = -2.0L * logl(static_cast<long double>(u));
         if (u == 1.0) { if (std::fabs(aa) > 1e-15) e_log = 1e30; }
         else { const double e = ulp_err(aa, want_a); if (e > e_log) e_log = e; }
@@ -97,12 +98,27 @@ int main(int argc, char **argv)
             if (band > e_band) e_band = band;
         }
     }
+    // the top of the uniform's range, one by one: u = 1 - j 2^-53, j = 0 .. 2^16 (the chunk that holds u = 1 and its
+    // neighbour), and the values around every power of two, where the chunk index wraps
+    for (uint64_t j = 0; j < 65536; ++j) {
+        const uint64_t v = (1ull << 53) - 1 - j;
+        const double u = std::fma(static_cast<double>(v), 0x1p-53, 0x1p-53);
+        const double aa = neg2log(u, T.log_tab);
+        if (!(aa > 0.0) || !(sqrt_scaled(aa, 0.0126) >= 0.0)) e_pos = 1.0;
+    }
+    for (int e = 1; e <= 52; ++e)
+        for (int64_t d = -4; d <= 4; ++d) {
+            const int64_t v = (int64_t(1) << e) + d;
+            if (v < 0) continue;
+            const double u = std::fma(static_cast<double>(v), 0x1p-53, 0x1p-53);
+            if (!(neg2log(u, T.log_tab) > 0.0)) e_pos = 1.0;
+        }
     // saturation instead of wrap-around: a huge exponent gives inf / 0, never a finite wrong value
     {
         const double big = mul_exp(1.0, 800.0, T.exp_hi_tab, T.exp_lo_tab), tiny = mul_exp(1.0, -800.0, T.exp_hi_tab, T.exp_lo_tab);
         if (!std::isinf(big) || tiny != 0.0) e_exp = 1e30;
     }
     std::printf("{\"n\": %ld, \"uniform_mismatch\": %g, \"neg2log_ulp\": %.3f, \"sqrt_ulp\": %.3f, \"sin_abs\": %.3g, "
-                "\"cos_abs\": %.3g, \"mul_exp_ulp\": %.3f, \"product252_ulp\": %.3f, \"mul_exp_wide_ulp_per_unit_x\": %.3f, \"sqrt_scaled_ulp\": %.3f, \"barrier_band_used\": %.4f}\n", n, e_u, e_log, e_sqrt, e_sin, e_cos, e_exp, e_prod, e_wide, e_sqs, e_band);
+                "\"cos_abs\": %.3g, \"mul_exp_ulp\": %.3f, \"product252_ulp\": %.3f, \"mul_exp_wide_ulp_per_unit_x\": %.3f, \"sqrt_scaled_ulp\": %.3f, \"barrier_band_used\": %.4f, \"neg2log_nonpositive\": %g}\n", n, e_u, e_log, e_sqrt, e_sin, e_cos, e_exp, e_prod, e_wide, e_sqs, e_band, e_pos);
     return 0;
 }

@@ -17,6 +17,7 @@ def test_fast64_accuracy_against_long_double_libm(tmp_path):
     assert r["neg2log_ulp"] <= 2.0
     assert r["sqrt_ulp"] <= 1.0
     assert r["sqrt_scaled_ulp"] <= 2.0                   # k sqrt(a) in six operations (one cubic step)
+    assert r["neg2log_nonpositive"] == 0                 # -2 ln u > 0 for every u in (0, 1]: the radius needs no clamp
     assert r["sin_abs"] <= 2.5e-16 and r["cos_abs"] <= 2.5e-16
     assert r["mul_exp_ulp"] <= 4.5                       # one factor S e^x, |x| <= 1: 2 table entries + 3 multiplies
     assert r["mul_exp_wide_ulp_per_unit_x"] <= 3.5       # |x| up to 300: the error grows with the exponent's own ulp

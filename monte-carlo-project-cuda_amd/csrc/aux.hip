@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
     constexpr int kRowsPerLoad = kWave / TS;   // path rows one wave-wide scalar-element load covers (non-VEC path)
     constexpr int kPad = 16 / sizeof(T);       // one 16-byte vector of padding: rows stay 16-byte aligned
     __shared__ alignas(16) T tile[kWaves][kWave][TS + kPad];
-    const StepConsts<T> &c = a.c;
+    const StepConsts<T> c = resident(a.c);
     const MathCtx<T> m = MathCtx<T>::init();
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -207,11 +207,12 @@ __global__ __launch_bounds__(kBlock) void normals_kernel(uint64_t seed, uint64_t
 {
     constexpr int NB = Normals<T>::kPerBlock;
     const MathCtx<T> m = MathCtx<T>::init();
+    const PhiloxKeys key = PhiloxKeys::make(seed);
     const uint64_t n_blocks = (n + NB - 1) / NB;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; k < n_blocks; k += stride) {
         Normals<T> nrm;
-        nrm.fill(m, seed, 0, k);
+        nrm.fill(m, key, 0, k);
         const uint64_t base = k * NB;
         if (vec_ok && base + NB <= n) {
             using VT = T __attribute__((ext_vector_type(NB)));

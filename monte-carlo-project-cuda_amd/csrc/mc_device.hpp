@@ -27,48 +27,78 @@ struct U4 {
     uint32_t x, y, z, w;
 };
 
-__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                            uint32_t k1)
+// A value copied into a vector register, opaque to the optimiser.  Why: on gfx950 a full-rate 32-bit VALU
+// instruction (v_xor / v_bitop3 / v_fma_f32 / v_mul_f32 ...) that reads a SCALAR register issues in 4 cycles instead of
+// 2 (tools/ubench_bank.hip -> profiles/r02_operand_costs.txt: v_bitop3 v,v,s 4.2 vs v,v,v 2.4; v_xor s,v 4.2 vs 2.2;
+// v_fma_f32 v,s,v 4.2 vs 2.4; literals and fp64 / multiply instructions are not affected).  hipcc keeps every
+// wave-uniform value in scalar registers, so the constants of the hot full-rate instructions — the Philox round keys,
+// the fp32 drift and volatility — are moved to vector registers once per kernel.
+__device__ __forceinline__ uint32_t vgpr_resident(uint32_t s)
 {
-    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-    // round 1 with plain xors, grouped so that the pair of inputs that is wave-uniform in every kernel here (the key
-    // word with the block counter's high word; the key word with the high product of the block counter's low word)
-    // is combined on the scalar unit: a three-input v_bitop3 would need two scalar operands, one more than a
-    // vector instruction may read, and cost a v_mov per block
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+__device__ __forceinline__ float vgpr_resident(float s)
+{
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+
+// The ten round-key pairs of Philox4x32-10 for one seed, in vector registers (20 VGPRs, built once per kernel).
+struct PhiloxKeys {
+    uint32_t k0[10], k1[10];
+    __device__ __forceinline__ static PhiloxKeys make(uint64_t seed)
+    {
+        constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+        PhiloxKeys k;
+        uint32_t a = static_cast<uint32_t>(seed), b = static_cast<uint32_t>(seed >> 32);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            k.k0[i] = vgpr_resident(a);
+            k.k1[i] = vgpr_resident(b);
+            a += W0;
+            b += W1;
+        }
+        return k;
+    }
+};
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, const PhiloxKeys &key)
+{
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    // round 1 with plain xors: in the path kernels c0 (block index) is wave-uniform and c1 (its high word) is zero, so
+    // one of the two three-input xors collapses and the compiler sees which inputs are scalar
     {
         const uint64_t p0 = static_cast<uint64_t>(M0) * c0;
         const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
-        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ (c1 ^ k0);
-        const uint32_t n2 = c3 ^ (static_cast<uint32_t>(p0 >> 32) ^ k1);
+        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ key.k0[0];
+        const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ (c3 ^ key.k1[0]);
         c1 = static_cast<uint32_t>(p1);
         c3 = static_cast<uint32_t>(p0);
         c0 = n0;
         c2 = n2;
-        k0 += W0;
-        k1 += W1;
     }
 #pragma unroll
     for (int i = 1; i < 10; ++i) {
         const uint64_t p0 = static_cast<uint64_t>(M0) * c0;
         const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
-        // three-input xor in one full-rate instruction (v_bitop3_b32, truth table 0x96)
-        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p1 >> 32), c1, k0, 0x96);
-        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p0 >> 32), c3, k1, 0x96);
+        // three-input xor in one full-rate instruction (v_bitop3_b32, truth table 0x96), all three inputs in VGPRs
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p1 >> 32), c1, key.k0[i], 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p0 >> 32), c3, key.k1[i], 0x96);
         c1 = static_cast<uint32_t>(p1);
         c3 = static_cast<uint32_t>(p0);
         c0 = n0;
         c2 = n2;
-        k0 += W0;
-        k1 += W1;
     }
     return U4{c0, c1, c2, c3};
 }
 
-__device__ __forceinline__ U4 philox_block(uint64_t seed, uint64_t subsequence, uint64_t block)
+__device__ __forceinline__ U4 philox_block(const PhiloxKeys &key, uint64_t subsequence, uint64_t block)
 {
     return philox4x32_10(static_cast<uint32_t>(block), static_cast<uint32_t>(block >> 32),
-                         static_cast<uint32_t>(subsequence), static_cast<uint32_t>(subsequence >> 32),
-                         static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+                         static_cast<uint32_t>(subsequence), static_cast<uint32_t>(subsequence >> 32), key);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -143,9 +173,10 @@ template <>
 struct Normals<float> {
     static constexpr int kPerBlock = 4;
     float z[4];
-    __device__ __forceinline__ void fill(const MathCtx<float> &, uint64_t seed, uint64_t subsequence, uint64_t block)
+    __device__ __forceinline__ void fill(const MathCtx<float> &, const PhiloxKeys &key, uint64_t subsequence,
+                                         uint64_t block)
     {
-        const U4 w = philox_block(seed, subsequence, block);
+        const U4 w = philox_block(key, subsequence, block);
         box_muller(w.x, w.y, z[0], z[1]);
         box_muller(w.z, w.w, z[2], z[3]);
     }
@@ -155,10 +186,10 @@ template <>
 struct Normals<double> {
     static constexpr int kPerBlock = 2;
     double z[2];
-    __device__ __forceinline__ void fill(const MathCtx<double> &m, uint64_t seed, uint64_t subsequence,
+    __device__ __forceinline__ void fill(const MathCtx<double> &m, const PhiloxKeys &key, uint64_t subsequence,
                                          uint64_t block)
     {
-        const U4 w = philox_block(seed, subsequence, block);
+        const U4 w = philox_block(key, subsequence, block);
         box_muller(w, m, z[0], z[1]);
     }
 };
@@ -182,6 +213,19 @@ struct StepConsts {
     int32_t P1, P2, Ik;
     uint32_t n_sim;  // steps to simulate = n_steps - Tk
 };
+
+// The step constants as the kernels' inner loops should read them: in fp32 the three constants of the full-rate
+// instructions (x = fma(sin, sv, drift), sv = r * vol_bm, the log-space update) go to vector registers — a scalar
+// operand would double those instructions' issue time (see vgpr_resident) — in fp64 nothing changes (fp64
+// instructions take four cycles whatever their operands).
+__device__ __forceinline__ StepConsts<float> resident(StepConsts<float> c)
+{
+    c.drift = vgpr_resident(c.drift);
+    c.vol = vgpr_resident(c.vol);
+    c.vol_bm = vgpr_resident(c.vol_bm);
+    return c;
+}
+__device__ __forceinline__ StepConsts<double> resident(const StepConsts<double> &c) { return c; }
 
 // Running price of one path.  fp32: the price itself, one v_exp_f32 and one multiply per step.  fp64: the start
 // price and the factored product of the step exponentials (f64::ExpAcc); value() evaluates it.
@@ -251,10 +295,10 @@ struct Exponents<float> {
         x0 = __builtin_fmaf(__builtin_amdgcn_sinf(rev), sv, c.drift);
         x1 = __builtin_fmaf(__builtin_amdgcn_cosf(rev), sv, c.drift);
     }
-    __device__ __forceinline__ void fill(const MathCtx<float> &, const StepConsts<float> &c, uint64_t seed,
+    __device__ __forceinline__ void fill(const MathCtx<float> &, const StepConsts<float> &c, const PhiloxKeys &key,
                                          uint64_t subsequence, uint64_t block)
     {
-        const U4 w = philox_block(seed, subsequence, block);
+        const U4 w = philox_block(key, subsequence, block);
         pair(w.x, w.y, c, x[0], x[1]);
         pair(w.z, w.w, c, x[2], x[3]);
     }
@@ -264,10 +308,10 @@ template <>
 struct Exponents<double> {
     static constexpr int kPerBlock = 2;
     double x[2];
-    __device__ __forceinline__ void fill(const MathCtx<double> &m, const StepConsts<double> &c, uint64_t seed,
+    __device__ __forceinline__ void fill(const MathCtx<double> &m, const StepConsts<double> &c, const PhiloxKeys &key,
                                          uint64_t subsequence, uint64_t block)
     {
-        const U4 w = philox_block(seed, subsequence, block);
+        const U4 w = philox_block(key, subsequence, block);
         const double u = f64::u53(w.x, w.y, 0x1p-53);
         const double sv = f64::sqrt_scaled(f64::neg2log(u, m.t.log_tab), c.vol_bm);
         double sn, cs;
@@ -338,7 +382,7 @@ __device__ __forceinline__ bool window_closed(int32_t count, int32_t count2, int
 // EARLY: leave the loop when the window has closed for the whole wavefront (off when the caller needs the
 // terminal price itself, i.e. for the S_T control variate).
 template <typename T, bool WINDOW, bool LOGSPACE, bool ANTI, bool EARLY = WINDOW>
-__device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, const MathCtx<T> &m, uint64_t seed,
+__device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &seed,
                                                      uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
                                                      T log_start = T(0))
 {
@@ -439,7 +483,7 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
 }
 
 template <typename T, bool WINDOW, bool LOGSPACE>
-__device__ __forceinline__ T simulate_path(const StepConsts<T> &c, const MathCtx<T> &m, uint64_t seed,
+__device__ __forceinline__ T simulate_path(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &seed,
                                            uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
                                            T log_start = T(0), uint32_t *steps_run = nullptr)
 {

@@ -63,6 +63,8 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
                                                           unsigned long long *__restrict__ queue)
 {
     const MathCtx<T> m = MathCtx<T>::init();
+    const PhiloxKeys key = PhiloxKeys::make(a.seed);
+    const StepConsts<T> c = resident(a.c);
     const int lane = threadIdx.x & (kWave - 1);
     double rec[kNmcRecord] = {0.0, 0.0, 0.0};  // sum of point prices, sum of squares, wave-steps executed (lane 0)
     for (;;) {
@@ -82,11 +84,11 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
             const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
             double acc = 0.0;
             uint32_t steps_run = 0;
-            if (!WINDOW || cnt0 <= a.c.P2) {
-                const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, a.c.S_start) : T(0);
+            if (!WINDOW || cnt0 <= c.P2) {
+                const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
                 for (uint32_t j = lane; j < a.n_inner; j += kWave)
                     acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(
-                        a.c, m, a.seed, point_id * a.n_inner + j, St0, cnt0, remaining, ls, &steps_run));
+                        c, m, key, point_id * a.n_inner + j, St0, cnt0, remaining, ls, &steps_run));
             }
             acc = wave_sum(acc);
             if (lane == 0) {
@@ -109,6 +111,8 @@ template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE>
 __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double *__restrict__ partials)
 {
     const MathCtx<T> m = MathCtx<T>::init();
+    const PhiloxKeys key = PhiloxKeys::make(a.seed);
+    const StepConsts<T> c = resident(a.c);
     double psum = 0.0, psumsq = 0.0, pwork = 0.0;
     for (uint64_t task = blockIdx.x; task < a.n_points; task += gridDim.x) {
         uint32_t step;
@@ -120,10 +124,10 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
         const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
         double acc = 0.0, work = 0.0;
         uint32_t steps_run = 0;
-        if (!WINDOW || cnt0 <= a.c.P2) {
-            const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, a.c.S_start) : T(0);
+        if (!WINDOW || cnt0 <= c.P2) {
+            const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
             for (uint32_t j = threadIdx.x; j < a.n_inner; j += kBlock)
-                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(a.c, m, a.seed, point_id * a.n_inner + j,
+                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, key, point_id * a.n_inner + j,
                                                                                St0, cnt0, remaining, ls, &steps_run));
         }
         // wave-steps: each wavefront's first lane runs every pass that wavefront makes
@@ -163,18 +167,20 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
     const MathCtx<T> m = MathCtx<T>::init();
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    const StepConsts<T> &c = a.c;
+    const StepConsts<T> c = resident(a.c);
     // owned paths: blockIdx.x, blockIdx.x + G, ...
     const uint64_t n_owned = a.n_local > blockIdx.x ? (a.n_local - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
 
     // ---- phase 1: outer trajectories of the owned paths (inc/nmc.cuh:144-202) ----
+    {
+    const PhiloxKeys outer_key = PhiloxKeys::make(outer_seed);   // its 20 registers are free again after this phase
     for (uint64_t i = threadIdx.x; i < n_owned; i += kBlock) {
         const uint64_t path = blockIdx.x + i * gridDim.x;
         PathState<T> ps = PathState<T>::start(c.S_start);
         int32_t cnt = c.Ik;
         Exponents<T> ex;
         for (uint32_t step = 0; step < a.n_steps; ++step) {
-            if (step % NB == 0) ex.fill(m, c, outer_seed, a.path_offset + path, step / NB);
+            if (step % NB == 0) ex.fill(m, c, outer_key, a.path_offset + path, step / NB);
             T x = ex.x[0];
 #pragma unroll
             for (int j = 1; j < NB; ++j) x = (step % NB == static_cast<uint32_t>(j)) ? ex.x[j] : x;
@@ -187,7 +193,9 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
             if (WINDOW) counts[idx] = cnt;
         }
     }
+    }
     __syncthreads();  // workgroup-scope release/acquire: this workgroup reads only what it wrote
+    const PhiloxKeys key = PhiloxKeys::make(a.seed);
 
     // ---- phase 2: inner stage over the owned points, one wavefront per point, long tasks first ----
     double rec[kNmcRecord] = {0.0, 0.0, 0.0};
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
         if (!WINDOW || cnt0 <= c.P2) {
             const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
             for (uint32_t j = lane; j < a.n_inner; j += kWave)
-                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, a.seed, point_id * a.n_inner + j, St0,
+                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, key, point_id * a.n_inner + j, St0,
                                                                                cnt0, remaining, ls, &steps_run));
         }
         acc = wave_sum(acc);

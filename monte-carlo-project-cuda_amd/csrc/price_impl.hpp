@@ -40,13 +40,15 @@ __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *_
     constexpr bool ANTI = (VR & 1) != 0, CV = (VR & 2) != 0;
     constexpr int N = CV ? 5 : 2;
     const MathCtx<T> m = MathCtx<T>::init();
+    const PhiloxKeys key = PhiloxKeys::make(a.seed);
+    const StepConsts<T> c = resident(a.c);
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     double acc[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = 0.0;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_local; i += stride) {
         const Sample<T> smp = simulate_sample<T, WINDOW, LOGSPACE, ANTI, WINDOW && !CV>(
-            a.c, m, a.seed, a.path_offset + i, a.c.S_start, a.c.Ik, a.c.n_sim);
+            c, m, key, a.path_offset + i, c.S_start, c.Ik, c.n_sim);
         const double y = static_cast<double>(smp.pay);
         acc[0] += y;
         acc[1] = __builtin_fma(y, y, acc[1]);

@@ -60,12 +60,11 @@ __device__ __forceinline__ void store_row(E *__restrict__ row, OFF off, const E 
 // The paths of one thread (V consecutive ones starting at `base`) through all steps.  OFF = uint32_t when a whole
 // row is addressable with 32 bits (every realistic trajectory buffer), uint64_t otherwise.
 template <typename T, bool WINDOW, int LAYOUT, bool VEC, typename OFF>
-__device__ __forceinline__ void store_group(const StoreArgs<T> &a, const MathCtx<T> &m, uint64_t base, double &s,
-                                            double &s2)
+__device__ __forceinline__ void store_group(const StoreArgs<T> &a, const StepConsts<T> &c, const MathCtx<T> &m,
+                                            const PhiloxKeys &key, uint64_t base, double &s, double &s2)
 {
     constexpr int V = 16 / sizeof(T);
     constexpr int NB = Normals<T>::kPerBlock;
-    const StepConsts<T> &c = a.c;
     const uint32_t n_full = c.n_sim / NB;         // Philox blocks whose NB steps are all simulated
     const uint32_t rem = c.n_sim - n_full * NB;   // steps of the last, partial block
     const OFF off = static_cast<OFF>(base);
@@ -104,14 +103,14 @@ __device__ __forceinline__ void store_group(const StoreArgs<T> &a, const MathCtx
     for (uint32_t k = 0; k < n_full; ++k) {
         Exponents<T> nrm[V];
 #pragma unroll
-        for (int p = 0; p < V; ++p) nrm[p].fill(m, c, a.seed, a.path_offset + base + p, k);
+        for (int p = 0; p < V; ++p) nrm[p].fill(m, c, key, a.path_offset + base + p, k);
 #pragma unroll
         for (int j = 0; j < NB; ++j) advance(nrm, j, k * NB + j);
     }
     if (rem) {
         Exponents<T> nrm[V];
 #pragma unroll
-        for (int p = 0; p < V; ++p) nrm[p].fill(m, c, a.seed, a.path_offset + base + p, n_full);
+        for (int p = 0; p < V; ++p) nrm[p].fill(m, c, key, a.path_offset + base + p, n_full);
 #pragma unroll
         for (int j = 0; j < NB - 1; ++j)
             if (static_cast<uint32_t>(j) < rem) advance(nrm, j, n_full * NB + j);
@@ -137,13 +136,15 @@ __global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *_
 {
     constexpr int V = 16 / sizeof(T);
     const MathCtx<T> m = MathCtx<T>::init();
+    const PhiloxKeys key = PhiloxKeys::make(a.seed);
+    const StepConsts<T> c = resident(a.c);
     const uint64_t n_groups = (a.n_local + V - 1) / V;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     const bool narrow = a.n_local + V <= 0xffffffffull / 8;   // a row's byte offsets (prices or counts) fit 32 bits
     double s = 0.0, s2 = 0.0;
     for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; g < n_groups; g += stride) {
-        if (narrow) store_group<T, WINDOW, LAYOUT, VEC, uint32_t>(a, m, g * V, s, s2);
-        else store_group<T, WINDOW, LAYOUT, VEC, uint64_t>(a, m, g * V, s, s2);
+        if (narrow) store_group<T, WINDOW, LAYOUT, VEC, uint32_t>(a, c, m, key, g * V, s, s2);
+        else store_group<T, WINDOW, LAYOUT, VEC, uint64_t>(a, c, m, key, g * V, s, s2);
     }
     block_sum2<kBlock>(s, s2);
     if (threadIdx.x == 0) {

@@ -36,13 +36,19 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void probe_kernel(PriceArgs<T> a, double *__restrict__ partials,
                                                        uint64_t *__restrict__ stamps)
 {
+    // optional dynamic LDS (launch parameter): only there to cap the workgroups a CU can hold, for the occupancy sweep
+    extern __shared__ char occupancy_pad[];
+    if (threadIdx.x == 1023) occupancy_pad[0] = 0;   // never true for 256-thread blocks: keeps the symbol referenced
+    const uint64_t w_entry = __builtin_amdgcn_s_memrealtime();   // kernel entry, before the LDS tables are filled
     const MathCtx<T> m = MathCtx<T>::init();
+    const PhiloxKeys key = PhiloxKeys::make(a.seed);
+    const StepConsts<T> c = resident(a.c);
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     double acc[2] = {0.0, 0.0};
     const uint64_t t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_local; i += stride) {
         const Sample<T> smp =
-            simulate_sample<T, false, false, false>(a.c, m, a.seed, a.path_offset + i, a.c.S_start, a.c.Ik, a.c.n_sim);
+            simulate_sample<T, false, false, false>(c, m, key, a.path_offset + i, c.S_start, c.Ik, c.n_sim);
         const double y = static_cast<double>(smp.pay);
         acc[0] += y;
         acc[1] = __builtin_fma(y, y, acc[1]);
@@ -59,14 +65,14 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(PriceArgs<T> a, double *_
     if ((threadIdx.x & 63) == 0) {
         const uint64_t wave = static_cast<uint64_t>(blockIdx.x) * (kBlock / 64) + threadIdx.x / 64;
         stamps[4 * wave + 0] = t0;
-        stamps[4 * wave + 1] = t1;
+        stamps[4 * wave + 1] = t1 | ((w0 - w_entry) << 48);   // top 16 bits: 100 MHz ticks spent before the step loop
         stamps[4 * wave + 2] = w0;
         stamps[4 * wave + 3] = w1;
     }
 }
 
 template <typename T>
-static int run(const char *name, uint64_t n_paths, uint32_t n_steps, double seconds)
+static int run(const char *name, uint64_t n_paths, uint32_t n_steps, double seconds, uint32_t pad_bytes = 0)
 {
     PathJob j{};
     const double dt = 1.0 / n_steps, r = 0.1, v = 0.2;
@@ -98,7 +104,7 @@ static int run(const char *name, uint64_t n_paths, uint32_t n_steps, double seco
     while (true) {
         a.seed = 1234 + launches;
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(probe_kernel<T>, dim3(grid), dim3(kBlock), 0, 0, a, d_part, d_st);
+        hipLaunchKernelGGL(probe_kernel<T>, dim3(grid), dim3(kBlock), pad_bytes, 0, a, d_part, d_st);
         CK(hipEventRecord(e1, 0));
         ++launches;
         if (launches % 8 == 0) {
@@ -114,9 +120,11 @@ static int run(const char *name, uint64_t n_paths, uint32_t n_steps, double seco
     std::vector<double> part(2 * grid);
     CK(hipMemcpy(st.data(), d_st, st.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
     CK(hipMemcpy(part.data(), d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost));
-    std::vector<double> ghz(n_waves), cyc(n_waves);
+    std::vector<double> ghz(n_waves), cyc(n_waves), pre_ticks(n_waves);
     uint64_t tmin = ~0ull, tmax = 0, wmin = ~0ull, wmax = 0;
     for (uint64_t w = 0; w < n_waves; ++w) {
+        pre_ticks[w] = static_cast<double>(st[4 * w + 1] >> 48);
+        st[4 * w + 1] &= (1ull << 48) - 1;
         const double dc = static_cast<double>(st[4 * w + 1] - st[4 * w + 0]);
         const double dr = static_cast<double>(st[4 * w + 3] - st[4 * w + 2]);
         ghz[w] = dr > 0 ? dc / dr * 0.1 : 0.0;
@@ -126,6 +134,21 @@ static int run(const char *name, uint64_t n_paths, uint32_t n_steps, double seco
         (void)tmin;
         (void)tmax;
     }
+    // census: waves inside their step loop at three instants of the launch, on the 100 MHz s_memrealtime clock (the
+    // one counter all XCDs share; s_memtime is per-XCD)
+    uint64_t c_lo = ~0ull, c_hi = 0;
+    for (uint64_t w = 0; w < n_waves; ++w) {
+        c_lo = std::min(c_lo, st[4 * w + 2]);
+        c_hi = std::max(c_hi, st[4 * w + 3]);
+    }
+    double resident[3] = {0, 0, 0};
+    for (int q = 0; q < 3; ++q) {
+        const uint64_t t_q = c_lo + (c_hi - c_lo) * (q + 1) / 4;
+        uint64_t alive = 0;
+        for (uint64_t w = 0; w < n_waves; ++w) alive += (st[4 * w + 2] <= t_q && t_q < st[4 * w + 3]) ? 1 : 0;
+        resident[q] = static_cast<double>(alive) / 1024.0;
+    }
+    std::sort(pre_ticks.begin(), pre_ticks.end());
     std::sort(ghz.begin(), ghz.end());
     std::sort(cyc.begin(), cyc.end());
     std::sort(ms_all.begin(), ms_all.end());
@@ -138,13 +161,15 @@ static int run(const char *name, uint64_t n_paths, uint32_t n_steps, double seco
     const double cyc_per_wave_iter = span_ms * 1e-3 * clk * 1e9 / wave_iters_per_simd;
     double sum = 0.0;
     for (uint32_t b = 0; b < grid; ++b) sum += part[2 * b];
-    std::printf("{\"probe\": \"%s\", \"paths\": %llu, \"steps\": %u, \"launches\": %d, \"kernel_ms_median\": %.4f, "
+    std::printf("{\"probe\": \"%s\", \"lds_pad_bytes\": %u, \"paths\": %llu, \"steps\": %u, \"launches\": %d, \"kernel_ms_median\": %.4f, "
                 "\"span_ms_last_launch\": %.4f, \"in_kernel_clock_ghz_median\": %.4f, \"clock_ghz_p05\": %.4f, "
                 "\"clock_ghz_p95\": %.4f, \"wave_lifetime_cycles_median\": %.0f, \"path_steps_per_wave_iteration\": %d, "
-                "\"simd_cycles_per_wave_iteration\": %.1f, \"price\": %.6f}\n",
-                name, static_cast<unsigned long long>(n_paths), n_steps, launches, kernel_ms, span_ms, clk,
+                "\"simd_cycles_per_wave_iteration\": %.1f, \"waves_in_loop_per_simd\": [%.2f, %.2f, %.2f], "
+                "\"us_before_loop_median\": %.2f, \"us_before_loop_p95\": %.2f, \"price\": %.6f}\n",
+                name, pad_bytes, static_cast<unsigned long long>(n_paths), n_steps, launches, kernel_ms, span_ms, clk,
                 ghz[n_waves / 20], ghz[n_waves - 1 - n_waves / 20], cyc[n_waves / 2], Normals<T>::kPerBlock,
-                cyc_per_wave_iter, std::exp(-0.1) * sum / static_cast<double>(n_paths));
+                cyc_per_wave_iter, resident[0], resident[1], resident[2], pre_ticks[n_waves / 2] * 0.01,
+                pre_ticks[n_waves - 1 - n_waves / 20] * 0.01, std::exp(-0.1) * sum / static_cast<double>(n_paths));
     CK(hipFree(d_part));
     CK(hipFree(d_st));
     return 0;
@@ -157,5 +182,13 @@ int main(int argc, char **argv)
     const double seconds = argc > 3 ? std::atof(argv[3]) : 2.5;
     if (run<double>("price_f64", n_paths, n_steps, seconds)) return 1;
     if (run<float>("price_f32", n_paths, n_steps, seconds)) return 1;
+    if (argc > 4) {   // occupancy sweep: pad the workgroup's LDS so that fewer workgroups (= waves per SIMD) fit a CU
+        // fp64: 20.5 KB of tables per workgroup -> 7 per CU unpadded; 40 KB -> 4; 53 KB -> 3; 80 KB -> 2; 159 KB -> 1
+        for (uint32_t pad : {12u << 10, 20u << 10, 33u << 10, 60u << 10, 139u << 10})
+            if (run<double>("price_f64_occupancy", n_paths, n_steps, 0.6, pad)) return 1;
+        // fp32: no tables -> 8 per CU unpadded
+        for (uint32_t pad : {0u, 26u << 10, 39u << 10, 53u << 10, 80u << 10, 159u << 10})
+            if (run<float>("price_f32_occupancy", n_paths, n_steps, 0.4, pad)) return 1;
+    }
     return 0;
 }

@@ -5,7 +5,9 @@ The in-register path has no HBM traffic and no matrix work: its roofline is the 
 One "slot" = one full-rate wave64 VALU instruction = 2 cycles on a SIMD-32 (v_fma_f32, v_xor_b32,
 v_bitop3_b32 ...).  Instructions that issue slower are weighted by their measured cost
 (tools/ubench_valu.hip on MI355X -> profiles/r01_valu_issue_costs.json):
-    2 cycles  (1 slot)   f32 fma/mul/add, 32-bit add/sub/and/or/xor/bitop3, v_mov_b32
+    2 cycles  (1 slot)   f32 fma/mul/add, 32-bit add/sub/and/or/xor/bitop3, v_mov_b32 — with every source in a vector
+                         register, an inline constant or a literal; the SAME instruction reading a scalar register
+                         issues in 4 cycles (tools/ubench_bank.hip -> profiles/r02_operand_costs.txt), and is counted so
     4 cycles  (2 slots)  every fp64 arithmetic op, 32-bit integer multiplies incl. v_mad_u64_u32, shifts,
                          conversions, compares, v_cndmask, v_mov_b64, packed f32
     8 cycles  (4 slots)  f32 transcendentals (exp, log, sin, cos, sqrt, rcp, rsq)
@@ -30,6 +32,26 @@ HALF_PREFIX = ("v_mul_lo", "v_mul_hi", "v_mad_u64", "v_mad_i64", "v_mad_u32", "v
                "v_mov_b64", "v_and_or", "v_or3", "v_readlane", "v_readfirstlane", "v_ldexp", "v_frexp", "v_fract",
                "v_rndne", "v_trunc", "v_floor", "v_ceil", "v_add_co", "v_addc", "v_sub_co", "v_subb", "v_subrev_co",
                "v_subbrev", "v_pk_", "v_perm", "v_mbcnt", "v_max_f64", "v_min_f64")
+
+
+SGPR_OPERAND = re.compile(r"^(s\d+|s\[\d+:\d+\]|vcc(_lo|_hi)?|exec(_lo|_hi)?|m0|ttmp\d+)$")
+
+
+def reads_sgpr(line: str) -> bool:
+    """True when a source operand of the instruction is a scalar register (the first operand is the destination)."""
+    parts = line.split(None, 1)
+    if len(parts) < 2:
+        return False
+    ops = [o.strip() for o in parts[1].split(",")]
+    return any(SGPR_OPERAND.match(re.sub(r"^[-|]+|[|]+$", "", o.split()[0])) for o in ops[1:] if o)
+
+
+def line_cycles(line: str) -> int:
+    op = line.split()[0]
+    c = cycles(op)
+    if c == 2 and reads_sgpr(line):
+        return 4
+    return c
 
 
 def cycles(op: str) -> int:
@@ -102,10 +124,11 @@ def step_loop(asm: str, symbol: str):
                 blk = seg[b0:b1]
                 if not any("MCAMD_RARE_BLOCK" in x for x in blk):
                     body.extend(blk)
-            ins = [x.split()[0] for x in body if x and not x.startswith((".", ";")) and not x.endswith(":")]
+            ins = [x for x in body if x and not x.startswith((".", ";")) and not x.endswith(":")]
+            ops = [x.split()[0] for x in ins]
             # the step loop carries a whole Philox4x32-10 (20 32x32->64 multiplies, a few hoisted): other loops of a
             # kernel may hold a stray multiply (64-bit index arithmetic) and must not be mistaken for it
-            if ins.count("v_mad_u64_u32") + ins.count("v_mul_hi_u32") >= 12:
+            if ops.count("v_mad_u64_u32") + ops.count("v_mul_hi_u32") >= 12:
                 loops.append(ins)
     if not loops:
         raise SystemExit(f"no Philox loop in {symbol}")
@@ -130,9 +153,14 @@ def main():
     cost = measured_costs()
     for key, (src, sym, steps) in KERNELS.items():
         asm = cache.setdefault(src, asm_of(src))
-        ins = step_loop(asm, sym)
+        lines_ = step_loop(asm, sym)
+        # an instruction is keyed by its opcode, plus "(sgpr)" when a full-rate opcode reads a scalar register
+        keyed = [(l.split()[0] + (" (sgpr src)" if cycles(l.split()[0]) == 2 and reads_sgpr(l) else ""), line_cycles(l))
+                 for l in lines_]
+        ins = [k for k, _ in keyed]
+        cost_of = dict(keyed)
         cnt = collections.Counter(ins)
-        cyc = sum(cycles(op) * n for op, n in cnt.items())
+        cyc = sum(cost_of[op] * n for op, n in cnt.items())
         valu = sum(n for op, n in cnt.items() if op.startswith("v_"))
         slots = cyc / 2.0 / steps
         result[key] = round(slots, 2)
@@ -140,15 +168,16 @@ def main():
                                    "path_steps_per_iteration": steps}
         if cost is not None:   # the same count priced with the per-instruction costs measured on the chip
             result[key + "_detail"]["measured_cost_cycles_per_iteration"] = round(
-                sum(cost(op) * n for op, n in cnt.items() if op.startswith("v_")), 1)
+                sum((cost(op.split()[0]) + (2.0 if op.endswith("(sgpr src)") else 0.0)) * n
+                    for op, n in cnt.items() if op.startswith("v_")), 1)
         md.append(f"\n## {key}: `{sym}`\n")
         md.append(f"{len(ins)} instructions per loop iteration ({valu} VALU), {steps} path-steps per iteration, "
                   f"{cyc} issue cycles -> **{slots:.1f} slots per path-step**"
                   + (f" (priced with the issue costs measured on MI355X, r01_valu_issue_costs.json: "
                      f"{result[key + '_detail']['measured_cost_cycles_per_iteration']} cycles per iteration)" if cost else "") + "\n")
         md.append("| count | instruction | cycles each |\n|---:|---|---:|")
-        for op, n in sorted(cnt.items(), key=lambda kv: (-cycles(kv[0]) * kv[1], kv[0])):
-            md.append(f"| {n} | `{op}` | {cycles(op)} |")
+        for op, n in sorted(cnt.items(), key=lambda kv: (-cost_of[kv[0]] * kv[1], kv[0])):
+            md.append(f"| {n} | `{op}` | {cost_of[op]} |")
     # the id of the sources these counts were taken from (== mcamd_build_id() of a library built from them)
     import importlib.util
     spec = importlib.util.spec_from_file_location("mcamd_build", os.path.join(ROOT, "monte-carlo-project-cuda_amd", "build.py"))

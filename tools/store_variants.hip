@@ -31,13 +31,15 @@ using f4 = float __attribute__((ext_vector_type(4)));
 // EVERY: store one row in EVERY (1 = all rows; 2 = half the bytes with the same arithmetic; 0 = no trajectory stores):
 // separates "the arithmetic is slow" from "the arithmetic is slow WHILE the memory system is busy".
 template <int G, bool NT, int PRIO, int MINW, int EVERY = 1>
-__global__ __launch_bounds__(kBlock, MINW) void variant_kernel(StepConsts<float> c, uint64_t seed, uint64_t n_local,
+__global__ __launch_bounds__(kBlock, MINW) void variant_kernel(StepConsts<float> c_arg, uint64_t seed, uint64_t n_local,
                                                                float *__restrict__ traj, float *__restrict__ payoffs,
                                                                double *__restrict__ partials,
                                                                uint64_t *__restrict__ stamps)
 {
     constexpr int V = 4, NB = 4;
     const MathCtx<float> m = MathCtx<float>::init();
+    const PhiloxKeys key = PhiloxKeys::make(seed);
+    const StepConsts<float> c = resident(c_arg);
     // diagnostic stamps (this harness only): shader cycles and 100 MHz ticks around the wave's whole life
     const uint64_t t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
     const uint64_t n_groups = n_local / V;                       // n_local % (V * G * 64) == 0 assumed by the harness
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(kBlock, MINW) void variant_kernel(StepConsts<float>
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int p = 0; p < V; ++p) ex[g][p].fill(m, c, seed, base[g] + p, k);
+                for (int p = 0; p < V; ++p) ex[g][p].fill(m, c, key, base[g] + p, k);
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 f4 pack[G];

@@ -11,7 +11,10 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-constexpr int UNROLL = 32;
+#ifndef MCAMD_UBENCH_UNROLL
+#define MCAMD_UBENCH_UNROLL 32
+#endif
+constexpr int UNROLL = MCAMD_UBENCH_UNROLL;  // instructions per loop trip (multiple of 8)
 
 // Each kernel: ITERS x UNROLL copies of one instruction on 8 rotating registers.
 #define KERNEL32(NAME, ASM)                                                                         \

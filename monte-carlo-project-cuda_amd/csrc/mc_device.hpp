@@ -115,9 +115,13 @@ template <>
 struct MathCtx<double> {
     f64::Tables t;
     double exp_c1;  // f64::kExpC1, resident in vector registers for the step loops
-    // Must be called by every thread of the workgroup (contains a barrier).
+    // Must be called by every thread of the workgroup (contains a barrier).  The copy runs at raised wave priority:
+    // the SIMD's arbiter serves the oldest wave first, and beside three or four older waves that keep the vector ALU
+    // saturated a newly launched wave otherwise needs ~58 us for these thirty instructions (tools/init_probe.hip:
+    // 1.4 us on an idle CU) — during which its workgroup holds LDS and registers without computing.
     __device__ __forceinline__ static MathCtx init()
     {
+        __builtin_amdgcn_s_setprio(3);
         __shared__ f64::D2 s_log[MCAMD_TAB_N];
         __shared__ f64::D2 s_sincos[MCAMD_TAB_N];
         __shared__ double s_exp_hi[256];
@@ -131,6 +135,7 @@ struct MathCtx<double> {
             s_exp_lo[i] = kExpLoTab[i];
         }
         __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
         return MathCtx{f64::Tables{s_log, s_sincos, s_exp_hi, s_exp_lo}, f64::exp_c1_resident()};
     }
 };

@@ -124,10 +124,28 @@ MC_HD uint32_t opaque(uint32_t x)
 // fma(v, c, c) is rocRAND's own expression; with c a power of two the result is exact.
 //   u = (v+1) 2^-53  -> c = 2^-53      (Box-Muller radius uniform, in (0, 1])
 //   q = (v+1) 2^-44  -> c = 2^-44      (256 x the angle uniform t = (v+1) 2^-52 in (0, 2])
+// y << 21 and y >> 11 from ONE instruction: the two halves of the 64-bit product y * 2^21 (v_mad_u64_u32, 4 issue
+// cycles; v_lshlrev_b32 alone is 4 on gfx950 and v_lshrrev_b32 2 more — profiles/r02_operand_costs.txt).
+struct Split21 {
+    uint32_t shl21, shr11;
+};
+MC_HD Split21 split21(uint32_t y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t p, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(carry) : "v"(y), "s"(0x200000u));
+    // opaque: otherwise the uint32 -> double conversion of the upper half is widened to a 64-bit conversion
+    return Split21{static_cast<uint32_t>(p), opaque(static_cast<uint32_t>(p >> 32))};
+#else
+    return Split21{y << 21, y >> 11};
+#endif
+}
+
 MC_HD double u53(uint32_t x, uint32_t y, double c)
 {
-    const uint32_t lo = x ^ (y << 21);
-    const uint32_t hi = y >> 11;
+    const Split21 sy = split21(y);
+    const uint32_t lo = x ^ sy.shl21;
+    const uint32_t hi = sy.shr11;
     // (lo + 1) c without a conversion: lo sits in the mantissa of 2^52, and fma(2^52 + lo, c, c - 2^52 c) is exact
     const double l = fma_usv(make_double(lo, 0x43300000u), c, c - 0x1p52 * c);
     // + hi 2^32 c: exact too, the sum is (v + 1) c with v + 1 <= 2^53
@@ -196,11 +214,18 @@ MC_HD double sqrt_scaled(double a, double k)
 // folded into the coefficients (kSinF1.., kCosF2..), so the polynomials run on f itself.
 MC_HD void sincos_bits(uint32_t z, uint32_t w, const D2 *tab, double &s, double &c)
 {
-    w = opaque(w);
-    const uint32_t lo = z ^ (w << 21);
-    const uint32_t hi = ((w >> 11) & 0xfffu) | 0x43300000u;
+    const Split21 sw = split21(w);
+    const uint32_t lo = z ^ sw.shl21;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (a & 0xfff) | 0x43300000 as one full-rate v_bitop3_b32 on vector-register constants (v_and_or_b32 and v_bfe_u32
+    // issue in 4 cycles, and so does any full-rate instruction reading a scalar register)
+    uint32_t hi;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(hi) : "v"(sw.shr11), "v"(0xfffu), "v"(0x43300000u));
+#else
+    const uint32_t hi = (sw.shr11 & 0xfffu) | 0x43300000u;
+#endif
     const double f = fma_usv(make_double(lo, hi), 0x1p-44, 0x1p-44 - 256.5);
-    const D2 e = *reinterpret_cast<const D2 *>(reinterpret_cast<const char *>(tab) + ((w >> 19) & 0x1ff0u));
+    const D2 e = *reinterpret_cast<const D2 *>(reinterpret_cast<const char *>(tab) + ((sw.shr11 >> 8) & 0x1ff0u));
     const double ff = f * f;
     double sp = fma_usv(ff, kSinF5, kSinF3);
     sp = fma_vvs(ff, sp, kSinF1);

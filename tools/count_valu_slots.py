@@ -8,8 +8,10 @@ v_bitop3_b32 ...).  Instructions that issue slower are weighted by their measure
     2 cycles  (1 slot)   f32 fma/mul/add, 32-bit add/sub/and/or/xor/bitop3, v_mov_b32 — with every source in a vector
                          register, an inline constant or a literal; the SAME instruction reading a scalar register
                          issues in 4 cycles (tools/ubench_bank.hip -> profiles/r02_operand_costs.txt), and is counted so
-    4 cycles  (2 slots)  every fp64 arithmetic op, 32-bit integer multiplies incl. v_mad_u64_u32, shifts,
-                         conversions, compares, v_cndmask, v_mov_b64, packed f32
+    4 cycles  (2 slots)  every fp64 arithmetic op, 32-bit integer multiplies incl. v_mad_u64_u32, LEFT shifts
+                         (v_lshlrev_b32, v_lshl_add/or; the right shifts v_lshrrev_b32 / v_ashrrev_i32 are full rate),
+                         v_bfe, v_perm, v_and_or, v_add3, SDWA forms, 64-bit shifts, conversions, compares, v_cndmask,
+                         v_mov_b64, packed f32
     8 cycles  (4 slots)  f32 transcendentals (exp, log, sin, cos, sqrt, rcp, rsq)
    16 cycles  (8 slots)  v_rcp_f64 / v_rsq_f64 / v_sqrt_f64
 The tool compiles csrc/price_f64.hip, csrc/price_f32.hip and csrc/store.hip to assembly with the build's flags, finds the step
@@ -28,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "monte-carlo-project-cuda_amd", "csrc")
 
 HALF_PREFIX = ("v_mul_lo", "v_mul_hi", "v_mad_u64", "v_mad_i64", "v_mad_u32", "v_mul_u32", "v_mul_i32", "v_cvt",
-               "v_cndmask", "v_cmp", "v_lshl", "v_lshr", "v_ashr", "v_alignbit", "v_add3", "v_bfe", "v_bfi",
+               "v_cndmask", "v_cmp", "v_lshl", "v_alignbit", "v_add3", "v_bfe", "v_bfi",
                "v_mov_b64", "v_and_or", "v_or3", "v_readlane", "v_readfirstlane", "v_ldexp", "v_frexp", "v_fract",
                "v_rndne", "v_trunc", "v_floor", "v_ceil", "v_add_co", "v_addc", "v_sub_co", "v_subb", "v_subrev_co",
                "v_subbrev", "v_pk_", "v_perm", "v_mbcnt", "v_max_f64", "v_min_f64")
@@ -61,7 +63,7 @@ def cycles(op: str) -> int:
         return 16
     if re.match(r"v_(exp|log|sin|cos|sqrt|rcp|rsq)_f32", op):
         return 8
-    if "_f64" in op or op.startswith(HALF_PREFIX):
+    if "_f64" in op or "_b64" in op or "_i64" in op or "_u64" in op or op.endswith("_sdwa") or op.startswith(HALF_PREFIX):
         return 4
     return 2
 

@@ -69,6 +69,41 @@ KERNEL(mix_fma64_exp, INITB, "v_fma_f64 v[40:41], v[44:45], v[46:47], v[50:51]\n
 KERNEL(mix_fma32_exp, INITB, "v_fma_f32 v40, v44, v45, v46\n v_exp_f32 v60, v61", CL)
 KERNEL(mix_fma64_ds, INITB, "v_fma_f64 v[40:41], v[44:45], v[46:47], v[50:51]\n v_fma_f64 v[42:43], v[44:45], v[46:47], v[50:51]\n v_fma_f64 v[58:59], v[44:45], v[46:47], v[50:51]", CL)
 
+// operand forms of the integer / shift / conversion instructions of the fp64 loop: inline constant vs literal vs register
+KERNEL(lshl_inl, INITB, "v_lshlrev_b32 v40, 3, v61", CL)
+KERNEL(lshl_vv, INITB, "v_lshlrev_b32 v40, v60, v61", CL)
+KERNEL(lshr_inl, INITB, "v_lshrrev_b32 v40, 8, v61", CL)
+KERNEL(ashr_inl, INITB, "v_ashrrev_i32 v40, 16, v61", CL)
+KERNEL(and_inl, INITB, "v_and_b32 v40, 15, v61", CL)
+KERNEL(and_lit, INITB, "v_and_b32 v40, 0xff0, v61", CL)
+KERNEL(and_vv, INITB, "v_and_b32 v40, v60, v61", CL)
+KERNEL(add_inl, INITB, "v_add_u32 v40, 1, v61", CL)
+KERNEL(add_vv, INITB, "v_add_u32 v40, v60, v61", CL)
+KERNEL(sub_vv, INITB, "v_sub_u32 v40, v60, v61", CL)
+KERNEL(or_vv, INITB, "v_or_b32 v40, v60, v61", CL)
+KERNEL(bfe_inl, INITB, "v_bfe_u32 v40, v61, 8, 8", CL)
+KERNEL(bfe_vv, INITB, "v_bfe_u32 v40, v61, v62, v63", CL)
+KERNEL(lshl_or_inl, INITB, "v_lshl_or_b32 v40, v61, 4, v62", CL)
+KERNEL(lshl_add_inl, INITB, "v_lshl_add_u32 v40, v61, 4, v62", CL)
+KERNEL(perm_vvv, INITB, "v_perm_b32 v40, v61, v62, v63", CL)
+KERNEL(alignbit_vvv, INITB, "v_alignbit_b32 v40, v61, v62, v63", CL)
+KERNEL(mov_sdwa, INITB, "v_mov_b32_sdwa v40, v61 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1", CL)
+KERNEL(lshl_sdwa, INITB, "v_lshlrev_b32_sdwa v40, v60, v61 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", CL)
+KERNEL(cvt_f64_u32, INITB, "v_cvt_f64_u32 v[40:41], v61", CL)
+KERNEL(cvt_f64_i32, INITB, "v_cvt_f64_i32 v[40:41], v61", CL)
+KERNEL(cvt_f32_u32, INITB, "v_cvt_f32_u32 v40, v61", CL)
+KERNEL(cvt_f32_ubyte, INITB, "v_cvt_f32_ubyte1 v40, v61", CL)
+KERNEL(fma64_inl, INITB, "v_fma_f64 v[40:41], v[44:45], 1.0, v[46:47]", CL)
+KERNEL(mul64_inl, INITB, "v_mul_f64 v[40:41], 0.5, v[44:45]", CL)
+KERNEL(mul32_inl, INITB, "v_mul_f32 v40, 2.0, v61", CL)
+KERNEL(fma32_inl, INITB, "v_fma_f32 v40, v61, 2.0, v62", CL)
+KERNEL(mov_b32, INITB, "v_mov_b32 v40, v61", CL)
+KERNEL(ldexp64_vv, INITB, "v_ldexp_f64 v[40:41], v[44:45], v60", CL)
+KERNEL(mix_mad_2bitop, INITB, "v_mad_u64_u32 v[42:43], vcc, v61, v62, v[56:57]\n v_bitop3_b32 v60, v61, v62, v63 bitop3:0x96\n v_bitop3_b32 v58, v61, v62, v63 bitop3:0x96", CL)
+KERNEL(mix_2mad_2bitop, INITB, "v_mad_u64_u32 v[42:43], vcc, v61, v62, v[56:57]\n v_mad_u64_u32 v[40:41], vcc, v61, v62, v[56:57]\n v_bitop3_b32 v60, v61, v62, v63 bitop3:0x96\n v_bitop3_b32 v58, v61, v62, v63 bitop3:0x96", CL)
+KERNEL(mix_4mad_4bitop, INITB, "v_mad_u64_u32 v[42:43], vcc, v61, v62, v[56:57]\n v_mad_u64_u32 v[40:41], vcc, v61, v62, v[56:57]\n v_mad_u64_u32 v[54:55], vcc, v61, v62, v[56:57]\n v_mad_u64_u32 v[52:53], vcc, v61, v62, v[56:57]\n v_bitop3_b32 v60, v61, v62, v63 bitop3:0x96\n v_bitop3_b32 v58, v61, v62, v63 bitop3:0x96\n v_bitop3_b32 v59, v61, v62, v63 bitop3:0x96\n v_bitop3_b32 v51, v61, v62, v63 bitop3:0x96", CL)
+KERNEL(mix_2fma64_2bitop, INITB, "v_fma_f64 v[40:41], v[44:45], v[46:47], v[50:51]\n v_fma_f64 v[42:43], v[44:45], v[46:47], v[50:51]\n v_bitop3_b32 v60, v61, v62, v63 bitop3:0x96\n v_bitop3_b32 v58, v61, v62, v63 bitop3:0x96", CL)
+
 struct E { const char *n; void (*f)(uint32_t *, int); };
 int main()
 {
@@ -84,7 +119,13 @@ int main()
               {"mad_vvs", mad_vvs}, {"mad_2same", mad_2same},
               {"mix_fma64_bitop(2)", mix_fma64_bitop}, {"mix_fma64_mad(2)", mix_fma64_mad}, {"mix_mad_bitop(2)", mix_mad_bitop},
               {"mix_fma64_2bitop(3)", mix_fma64_2bitop}, {"mix_fma64_bitop_sgpr(2)", mix_fma64_bitop_sgpr}, {"dep_fma64", dep_fma64},
-              {"dep_mad_bitop(2)", dep_mad_bitop}, {"mix_fma64_exp(2)", mix_fma64_exp}, {"mix_fma32_exp(2)", mix_fma32_exp}, {"3x_fma64(3)", mix_fma64_ds}};
+              {"dep_mad_bitop(2)", dep_mad_bitop}, {"mix_fma64_exp(2)", mix_fma64_exp}, {"mix_fma32_exp(2)", mix_fma32_exp}, {"3x_fma64(3)", mix_fma64_ds},
+              {"lshl_inl", lshl_inl}, {"lshl_vv", lshl_vv}, {"lshr_inl", lshr_inl}, {"ashr_inl", ashr_inl}, {"and_inl", and_inl}, {"and_lit", and_lit},
+              {"and_vv", and_vv}, {"add_inl", add_inl}, {"add_vv", add_vv}, {"sub_vv", sub_vv}, {"or_vv", or_vv}, {"bfe_inl", bfe_inl}, {"bfe_vv", bfe_vv},
+              {"lshl_or_inl", lshl_or_inl}, {"lshl_add_inl", lshl_add_inl}, {"perm_vvv", perm_vvv}, {"alignbit_vvv", alignbit_vvv}, {"mov_sdwa", mov_sdwa},
+              {"lshl_sdwa", lshl_sdwa}, {"cvt_f64_u32", cvt_f64_u32}, {"cvt_f64_i32", cvt_f64_i32}, {"cvt_f32_u32", cvt_f32_u32}, {"cvt_f32_ubyte1", cvt_f32_ubyte},
+              {"fma64_inl", fma64_inl}, {"mul64_inl", mul64_inl}, {"mul32_inl", mul32_inl}, {"fma32_inl", fma32_inl}, {"mov_b32", mov_b32}, {"ldexp64_vv", ldexp64_vv},
+              {"mix_mad_2bitop(3)", mix_mad_2bitop}, {"mix_2mad_2bitop(4)", mix_2mad_2bitop}, {"mix_4mad_4bitop(8)", mix_4mad_4bitop}, {"mix_2fma64_2bitop(4)", mix_2fma64_2bitop}};
     for (auto &e : es) {
         float ms[2];
         const int it[2] = {500, 1500};

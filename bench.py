@@ -579,6 +579,20 @@ def main(argv=None):
                 sweep.append(e)
         line["sweep"] = sweep
 
+    # opt-in log-space stepping (MCAMD_FLAG_LOG_SPACE): same draws, ln(St/S0) carried instead of St.  Reported
+    # beside the headline, never as the headline (the headline is the reference's recurrence as written).  Measured
+    # BEFORE the store pass: the clock stays low for a while after 100 GB of stores, which cost this leg 13 % in r02's
+    # first artifacts.
+    if solo and wl == "european252":
+        ks = []
+        for i in range(12):
+            rl = ctx.price_paths(opt, capi.make_sim(n_total, n_steps, prec, 1234 + i, lo, per_gpu, flags=capi.FLAG_LOG_SPACE))
+            ks.append(rl.kernel_ms)
+        kms = sum(ks[2:]) / len(ks[2:])
+        line["log_space_mode"] = {"kernel_ms": kms, "paths_per_s_kernel": per_gpu / (kms / 1e3), "price": rl.price,
+                                  "std_err": rl.std_err, "abs_err_vs_bs": abs(rl.price - BS_EXACT),
+                                  "valu_slots_per_path_step": W.get("price_f64_logspace")}
+
     # bandwidth-bound path, one untimed pass of configs[2] beside the headline (N=1 only)
     if solo and wl == "european252" and not args.no_store_roofline:
         try:
@@ -607,18 +621,6 @@ def main(argv=None):
                 del buf, pay
         except Exception as e:  # the headline must survive a failure of the side measurement
             line["roofline_store"] = {"error": str(e)}
-
-    # opt-in log-space stepping (MCAMD_FLAG_LOG_SPACE): same draws, ln(St/S0) carried instead of St.  Reported
-    # beside the headline, never as the headline (the headline is the reference's recurrence as written).
-    if solo and wl == "european252":
-        ks = []
-        for i in range(4):
-            rl = ctx.price_paths(opt, capi.make_sim(n_total, n_steps, prec, 1234 + i, lo, per_gpu, flags=capi.FLAG_LOG_SPACE))
-            ks.append(rl.kernel_ms)
-        kms = sum(ks[1:]) / len(ks[1:])
-        line["log_space_mode"] = {"kernel_ms": kms, "paths_per_s_kernel": per_gpu / (kms / 1e3), "price": rl.price,
-                                  "std_err": rl.std_err, "abs_err_vs_bs": abs(rl.price - BS_EXACT),
-                                  "valu_slots_per_path_step": W.get("price_f64_logspace")}
 
     # "price within 1e-4 of closed form" on a 252-step BASELINE shape: the plain estimator would need > 2.6e10 paths
     # (sigma_payoff = 16.1), so this uses the engine's variance reduction — antithetic pairs + S_T control variate,

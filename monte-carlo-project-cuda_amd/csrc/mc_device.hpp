@@ -367,6 +367,9 @@ __device__ __forceinline__ double exp_of_logreturn(double S, double y, const Mat
 __device__ __forceinline__ float log_ratio(float a, float b) { return __builtin_amdgcn_logf(a / b); }  // log2
 __device__ __forceinline__ double log_ratio(double a, double b) { return log(a / b) * f64::kExpScale; }
 
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // What one sample contributes: its undiscounted payoff and the control variable S_T.  With ANTI the
 // sample is the antithetic pair (G, -G) of the same normals: both members are averaged.
 template <typename T>
@@ -404,10 +407,10 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
         Normals<T> nrm;
         auto step = [&](T G) {
             if (WINDOW) {
-                acc = __builtin_fma(G, c.vol, acc + c.drift);
+                acc = fma_t(G, c.vol, acc + c.drift);
                 count += (c.logB > acc) ? 1 : 0;
                 if (ANTI) {
-                    acc2 = __builtin_fma(-G, c.vol, acc2 + c.drift);
+                    acc2 = fma_t(-G, c.vol, acc2 + c.drift);
                     count2 += (c.logB > acc2) ? 1 : 0;
                 }
             } else {

@@ -28,6 +28,7 @@
 // successive inner paths of one thread is a defect and is not reproduced, and the
 // output is written, not atomically added to unzeroed memory.
 #include "path_consts.hpp"
+#include "nmc_compact.hpp"
 
 #include "mcamd.h"
 
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
     const PhiloxKeys key = PhiloxKeys::make(a.seed);
     const StepConsts<T> c = resident(a.c);
     const int lane = threadIdx.x & (kWave - 1);
+    __shared__ ParkedPaths<T, WINDOW> s_parked[kBlock / kWave];   // one buffer per wavefront (nmc_compact.hpp)
     double rec[kNmcRecord] = {0.0, 0.0, 0.0};  // sum of point prices, sum of squares, wave-steps executed (lane 0)
     for (;;) {
         unsigned long long first = 0;
@@ -84,11 +86,16 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
             const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
             double acc = 0.0;
             uint32_t steps_run = 0;
-            if (!WINDOW || cnt0 <= c.P2) {
-                const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
+            if constexpr (WINDOW) {
+                if (cnt0 <= c.P2) {
+                    const T ls = (LOGSPACE || sizeof(T) == 8) ? log_ratio(St0, c.S_start) : T(0);
+                    acc = point_sum_compacted<T, LOGSPACE>(c, m, key, point_id * a.n_inner, a.n_inner, St0, cnt0,
+                                                           remaining, ls, s_parked[threadIdx.x / kWave], steps_run);
+                }
+            } else {
                 for (uint32_t j = lane; j < a.n_inner; j += kWave)
                     acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(
-                        c, m, key, point_id * a.n_inner + j, St0, cnt0, remaining, ls, &steps_run));
+                        c, m, key, point_id * a.n_inner + j, St0, cnt0, remaining, T(0), &steps_run));
             }
             acc = wave_sum(acc);
             if (lane == 0) {
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
     const uint64_t n_tasks = n_owned * a.n_steps;
     // the workgroup's wavefronts pull its tasks from a counter in LDS (same reason as nmc_wave_kernel's queue)
     __shared__ unsigned int s_next;
+    __shared__ ParkedPaths<T, WINDOW> s_parked[kWaves];   // one buffer per wavefront (nmc_compact.hpp)
     if (threadIdx.x == 0) s_next = 0;
     __syncthreads();
     (void)wave;
@@ -220,11 +228,16 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
         const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
         double acc = 0.0;
         uint32_t steps_run = 0;
-        if (!WINDOW || cnt0 <= c.P2) {
-            const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
+        if constexpr (WINDOW) {
+            if (cnt0 <= c.P2) {
+                const T ls = (LOGSPACE || sizeof(T) == 8) ? log_ratio(St0, c.S_start) : T(0);
+                acc = point_sum_compacted<T, LOGSPACE>(c, m, key, point_id * a.n_inner, a.n_inner, St0, cnt0, remaining,
+                                                       ls, s_parked[wave], steps_run);
+            }
+        } else {
             for (uint32_t j = lane; j < a.n_inner; j += kWave)
                 acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, key, point_id * a.n_inner + j, St0,
-                                                                               cnt0, remaining, ls, &steps_run));
+                                                                               cnt0, remaining, T(0), &steps_run));
         }
         acc = wave_sum(acc);
         if (lane == 0) {

@@ -1,0 +1,244 @@
+// nmc_compact.hpp — the continuation paths of ONE nested-MC point, run by one wavefront with lane compaction.
+//
+// With a barrier window (inc/nmc.cuh:47-66: payoff only while P1 <= count <= P2) a continuation path is over as
+// soon as its count passes P2, and most are after a few dozen steps — but the few that climbed above the barrier
+// live to maturity, and a wavefront that waits for its last lane runs ~250 steps with two or three lanes working
+// (measured on BASELINE configs[3] with the reference's window B = 120, P1 = 10, P2 = 50: 36 % of the executed
+// lane-steps belong to paths that are still alive).  So the wavefront does not wait: once kCompactBelow or fewer
+// of its lanes are still running, those lanes park their path (product, exponent, count, path index, next Philox
+// block: 32 bytes in fp64) in the wavefront's LDS buffer and the wavefront starts the next 64 fresh paths; whenever
+// 64 parked paths have gathered they are resumed together, full width, under the same rule.  Philox is
+// counter-based, so a resumed path continues its own stream at its own block whatever lane it lands in:
+// every path's payoff is bit-identical to the uncompacted loop, only the summation order of the point's mean
+// changes (deterministically: the schedule depends on the point alone, not on timing).
+#pragma once
+
+#include "mc_device.hpp"
+
+namespace mcamd {
+
+constexpr uint32_t kCompactBelow = 16;                       // hand over when this many lanes or fewer still run
+constexpr uint32_t kSurvivorCap = kWave + kCompactBelow;     // at most 63 parked + one hand-over
+
+// One wavefront's parked paths (structure of arrays: lane-consecutive slots, conflict-free).
+template <typename T>
+struct SurvivorBuf {
+    T a[kSurvivorCap];             // fp64 product form: P;  fp32: St;  log-space: ln(St / S_start)
+    T b[kSurvivorCap];             // fp64 product form: kq (barrier accumulator);  unused otherwise
+    int32_t k[kSurvivorCap];       // fp64 product form: integer exponent;  unused otherwise
+    int32_t count[kSurvivorCap];
+    uint32_t j[kSurvivorCap];      // index of the path among the point's continuation paths
+    uint32_t blk[kSurvivorCap];    // next Philox block of its stream
+};
+
+// What a kernel declares in LDS per wavefront: the buffer when there is a window, nothing otherwise.
+template <typename T, bool WINDOW>
+struct ParkedPaths : SurvivorBuf<T> {};
+template <typename T>
+struct ParkedPaths<T, false> {};
+
+// A continuation path in flight.
+template <typename T>
+struct InnerLane {
+    PathState<T> ps;   // product form
+    T acc;             // log-space form
+    int32_t count;
+    uint32_t j, blk;
+    bool alive;        // the lane holds a path whose window is still open
+};
+
+__device__ __forceinline__ void park(SurvivorBuf<float> &buf, uint32_t slot, const InnerLane<float> &L, bool logspace)
+{
+    buf.a[slot] = logspace ? L.acc : L.ps.St;
+}
+__device__ __forceinline__ void unpark(const SurvivorBuf<float> &buf, uint32_t slot, InnerLane<float> &L, bool logspace)
+{
+    if (logspace) L.acc = buf.a[slot];
+    else L.ps.St = buf.a[slot];
+}
+__device__ __forceinline__ void park(SurvivorBuf<double> &buf, uint32_t slot, const InnerLane<double> &L, bool logspace)
+{
+    if (logspace) {
+        buf.a[slot] = L.acc;
+    } else {
+        buf.a[slot] = L.ps.a.P;
+        buf.b[slot] = L.ps.kq;
+        buf.k[slot] = L.ps.a.k;
+    }
+}
+__device__ __forceinline__ void unpark(const SurvivorBuf<double> &buf, uint32_t slot, InnerLane<double> &L, bool logspace)
+{
+    if (logspace) {
+        L.acc = buf.a[slot];
+    } else {
+        L.ps.a.P = buf.a[slot];
+        L.ps.kq = buf.b[slot];
+        L.ps.a.k = buf.k[slot];
+    }
+}
+
+// LDS traffic between lanes of one wavefront: the hardware serves a wavefront's LDS instructions in order; this
+// keeps the compiler from moving them across the hand-over.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One step of a continuation path: the GBM update and the barrier count (inc/nmc.cuh:56-58).
+template <typename T, bool LOGSPACE>
+__device__ __forceinline__ void inner_step(const StepConsts<T> &c, const MathCtx<T> &m, InnerLane<T> &L, T x_or_z)
+{
+    if (LOGSPACE) {
+        L.acc = fma_t(x_or_z, c.vol, L.acc + c.drift);
+        L.count += (c.logB > L.acc) ? 1 : 0;
+    } else {
+        L.ps.step(x_or_z, m);
+        L.count += L.ps.below_barrier(c, m) ? 1 : 0;
+    }
+}
+
+// The draws of one Philox block of path L.j, as inner_step consumes them: exponents (product form) or normals.
+template <typename T, bool LOGSPACE>
+struct BlockDraws {
+    T v[Normals<T>::kPerBlock];
+    __device__ __forceinline__ void fill(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
+                                         uint64_t subsequence, uint32_t block)
+    {
+        constexpr int NB = Normals<T>::kPerBlock;
+        if (LOGSPACE) {
+            Normals<T> nrm;
+            nrm.fill(m, key, subsequence, block);
+#pragma unroll
+            for (int s = 0; s < NB; ++s) v[s] = nrm.z[s];
+        } else {
+            Exponents<T> ex;
+            ex.fill(m, c, key, subsequence, block);
+#pragma unroll
+            for (int s = 0; s < NB; ++s) v[s] = ex.x[s];
+        }
+    }
+};
+
+// Runs the wavefront's paths through their FULL Philox blocks (n_full of them per path) until none is left running,
+// or — unless to_the_end — until kCompactBelow or fewer are.  UNIFORM: every running lane is at the same block (fresh
+// paths), so the block index stays scalar and the first Philox round keeps its scalar half.
+template <typename T, bool LOGSPACE, bool UNIFORM>
+__device__ __forceinline__ void run_batch(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
+                                          uint64_t first_subsequence, InnerLane<T> &L, uint32_t n_full, bool to_the_end,
+                                          uint32_t &wave_steps)
+{
+    constexpr int NB = Normals<T>::kPerBlock;
+    uint32_t kb = 0;
+    for (;;) {
+        const uint32_t block = UNIFORM ? kb : L.blk;
+        const bool run = L.alive && block < n_full;
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(run);
+        if (mask == 0) break;
+        if (!to_the_end && static_cast<uint32_t>(__builtin_popcountll(mask)) <= kCompactBelow) break;
+        if (run) {
+            BlockDraws<T, LOGSPACE> d;
+            d.fill(c, m, key, first_subsequence + L.j, block);
+#pragma unroll
+            for (int s = 0; s < NB; ++s) inner_step<T, LOGSPACE>(c, m, L, d.v[s]);
+            L.alive = L.count <= c.P2;
+            if (!UNIFORM) ++L.blk;
+        }
+        if (UNIFORM) ++kb;
+        wave_steps += NB;
+    }
+    if (UNIFORM) L.blk = kb;
+}
+
+// Sum of the window payoffs of the point's n_inner continuation paths (this lane's share: the caller adds the
+// lanes up).  Streams: path j uses Philox subsequence first_subsequence + j, as the uncompacted loop does.
+template <typename T, bool LOGSPACE>
+__device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
+                                                      uint64_t first_subsequence, uint32_t n_inner, T St0, int32_t cnt0,
+                                                      uint32_t remaining, T log_start, SurvivorBuf<T> &buf,
+                                                      uint32_t &wave_steps)
+{
+    constexpr int NB = Normals<T>::kPerBlock;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t n_full = remaining / NB;
+    const uint32_t rem = remaining - n_full * NB;
+    double sum = 0.0;
+    uint32_t parked = 0;   // wave-uniform
+
+    InnerLane<T> L;
+    L.ps = PathState<T>::start(St0);
+
+    // finished paths take the steps of the partial last block (rem of them) and pay; paths still running wait in
+    // the buffer
+    auto settle = [&]() {
+        if (L.alive && L.blk >= n_full) {
+            if (rem != 0) {
+                BlockDraws<T, LOGSPACE> d;
+                d.fill(c, m, key, first_subsequence + L.j, n_full);
+#pragma unroll
+                for (int s = 0; s < NB - 1; ++s)
+                    if (static_cast<uint32_t>(s) < rem) inner_step<T, LOGSPACE>(c, m, L, d.v[s]);
+            }
+            const T St = LOGSPACE ? exp_of_logreturn(c.S_start, L.acc, m) : L.ps.value(m);
+            sum += static_cast<double>(payoff<T, true>(St, L.count, c));
+        }
+        if (rem != 0 && __builtin_amdgcn_ballot_w64(L.alive && L.blk >= n_full) != 0) wave_steps += rem;
+        const bool waits = L.alive && L.blk < n_full;
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(waits);
+        if (mask != 0) {
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+            if (waits) {
+                const uint32_t slot = parked + below;
+                park(buf, slot, L, LOGSPACE);
+                buf.count[slot] = L.count;
+                buf.j[slot] = L.j;
+                buf.blk[slot] = L.blk;
+            }
+            parked += static_cast<uint32_t>(__builtin_popcountll(mask));
+            wave_lds_fence();
+        }
+    };
+    // resumes the last `take` parked paths, one per lane
+    auto resume = [&](uint32_t take) {
+        parked -= take;
+        L.alive = lane < take;
+        if (L.alive) {
+            const uint32_t slot = parked + lane;
+            unpark(buf, slot, L, LOGSPACE);
+            L.count = buf.count[slot];
+            L.j = buf.j[slot];
+            L.blk = buf.blk[slot];
+        }
+        wave_lds_fence();
+    };
+
+    for (uint32_t j0 = 0;;) {
+        if (j0 < n_inner) {   // the next 64 fresh paths
+            L.ps = PathState<T>::start(St0);
+            if (!LOGSPACE) L.ps.arm_barrier(c.logB - log_start);   // ln(B / St0) = ln(B / S_start) - ln(St0 / S_start)
+            L.acc = log_start;
+            L.count = cnt0;
+            L.j = j0 + lane;
+            L.blk = 0;
+            L.alive = L.j < n_inner;
+            run_batch<T, LOGSPACE, true>(c, m, key, first_subsequence, L, n_full, false, wave_steps);
+            settle();
+            j0 += kWave;
+        }
+        const bool none_fresh = j0 >= n_inner;
+        // a full wavefront of parked paths — or, when no fresh ones are left, whatever is parked
+        while (parked >= kWave || (none_fresh && parked != 0)) {
+            const uint32_t take = parked < kWave ? parked : kWave;
+            const bool last = none_fresh && parked == take;   // nothing will join them: run to the end
+            resume(take);
+            run_batch<T, LOGSPACE, false>(c, m, key, first_subsequence, L, n_full, last, wave_steps);
+            settle();
+        }
+        if (none_fresh) break;
+    }
+    return sum;
+}
+
+}  // namespace mcamd

@@ -42,10 +42,10 @@ template <typename T>
 struct InnerLane {
     PathState<T> ps;   // product form
     T acc;             // log-space form
-    int32_t count;
+    int32_t count;     // barrier count; kNoPath in a lane that holds no path (so "count <= P2" means: a live path)
     uint32_t j, blk;
-    bool alive;        // the lane holds a path whose window is still open
 };
+constexpr int32_t kNoPath = 0x7fffffff;
 
 __device__ __forceinline__ void park(SurvivorBuf<float> &buf, uint32_t slot, const InnerLane<float> &L, bool logspace)
 {
@@ -95,7 +95,7 @@ __device__ __forceinline__ void inner_step(const StepConsts<T> &c, const MathCtx
         L.count += (c.logB > L.acc) ? 1 : 0;
     } else {
         L.ps.step(x_or_z, m);
-        L.count += L.ps.below_barrier(c, m) ? 1 : 0;
+        L.count += L.ps.below_barrier(c, m);
     }
 }
 
@@ -121,34 +121,34 @@ struct BlockDraws {
     }
 };
 
-// Runs the wavefront's paths through their FULL Philox blocks (n_full of them per path) until none is left running,
-// or — unless to_the_end — until kCompactBelow or fewer are.  UNIFORM: every running lane is at the same block (fresh
-// paths), so the block index stays scalar and the first Philox round keeps its scalar half.
+// Runs the wavefront's paths through their FULL Philox blocks (n_full of them per path) until live_limit or fewer are
+// still running (0: to the end).  UNIFORM: every running lane is at the same block (fresh paths), so the block index
+// stays scalar and the first Philox round keeps its scalar half.
 template <typename T, bool LOGSPACE, bool UNIFORM>
 __device__ __forceinline__ void run_batch(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
-                                          uint64_t first_subsequence, InnerLane<T> &L, uint32_t n_full, bool to_the_end,
-                                          uint32_t &wave_steps)
+                                          uint64_t first_subsequence, InnerLane<T> &L, uint32_t n_full,
+                                          uint32_t live_limit, uint32_t &wave_steps)
 {
     constexpr int NB = Normals<T>::kPerBlock;
-    uint32_t kb = 0;
-    for (;;) {
-        const uint32_t block = UNIFORM ? kb : L.blk;
-        const bool run = L.alive && block < n_full;
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(run);
-        if (mask == 0) break;
-        if (!to_the_end && static_cast<uint32_t>(__builtin_popcountll(mask)) <= kCompactBelow) break;
+    const uint64_t subsequence = first_subsequence + L.j;
+    uint32_t kb = 0;   // blocks this call ran (wave-uniform); UNIFORM: also the block index of every running lane
+    for (; !UNIFORM || kb < n_full; ++kb) {
+        // liveness is read off the count every time (one compare straight into a lane mask) rather than carried
+        // as a flag, which the compiler would keep re-materialising in a vector register
+        const bool run = UNIFORM ? (L.count <= c.P2) : (L.count <= c.P2 && L.blk < n_full);
+        const uint32_t live = __builtin_amdgcn_readfirstlane(
+            static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(run))));
+        if (live <= live_limit) break;
         if (run) {
             BlockDraws<T, LOGSPACE> d;
-            d.fill(c, m, key, first_subsequence + L.j, block);
+            d.fill(c, m, key, subsequence, UNIFORM ? kb : L.blk);
 #pragma unroll
             for (int s = 0; s < NB; ++s) inner_step<T, LOGSPACE>(c, m, L, d.v[s]);
-            L.alive = L.count <= c.P2;
             if (!UNIFORM) ++L.blk;
         }
-        if (UNIFORM) ++kb;
-        wave_steps += NB;
     }
     if (UNIFORM) L.blk = kb;
+    wave_steps += static_cast<uint32_t>(NB) * static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(kb));
 }
 
 // Sum of the window payoffs of the point's n_inner continuation paths (this lane's share: the caller adds the
@@ -172,7 +172,7 @@ __device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, co
     // finished paths take the steps of the partial last block (rem of them) and pay; paths still running wait in
     // the buffer
     auto settle = [&]() {
-        if (L.alive && L.blk >= n_full) {
+        if (L.count <= c.P2 && L.blk >= n_full) {
             if (rem != 0) {
                 BlockDraws<T, LOGSPACE> d;
                 d.fill(c, m, key, first_subsequence + L.j, n_full);
@@ -183,8 +183,8 @@ __device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, co
             const T St = LOGSPACE ? exp_of_logreturn(c.S_start, L.acc, m) : L.ps.value(m);
             sum += static_cast<double>(payoff<T, true>(St, L.count, c));
         }
-        if (rem != 0 && __builtin_amdgcn_ballot_w64(L.alive && L.blk >= n_full) != 0) wave_steps += rem;
-        const bool waits = L.alive && L.blk < n_full;
+        if (rem != 0 && __builtin_amdgcn_ballot_w64(L.count <= c.P2 && L.blk >= n_full) != 0) wave_steps += rem;
+        const bool waits = L.count <= c.P2 && L.blk < n_full;
         const uint64_t mask = __builtin_amdgcn_ballot_w64(waits);
         if (mask != 0) {
             const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
@@ -203,8 +203,8 @@ __device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, co
     // resumes the last `take` parked paths, one per lane
     auto resume = [&](uint32_t take) {
         parked -= take;
-        L.alive = lane < take;
-        if (L.alive) {
+        L.count = kNoPath;
+        if (lane < take) {
             const uint32_t slot = parked + lane;
             unpark(buf, slot, L, LOGSPACE);
             L.count = buf.count[slot];
@@ -219,11 +219,10 @@ __device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, co
             L.ps = PathState<T>::start(St0);
             if (!LOGSPACE) L.ps.arm_barrier(c.logB - log_start);   // ln(B / St0) = ln(B / S_start) - ln(St0 / S_start)
             L.acc = log_start;
-            L.count = cnt0;
             L.j = j0 + lane;
+            L.count = L.j < n_inner ? cnt0 : kNoPath;
             L.blk = 0;
-            L.alive = L.j < n_inner;
-            run_batch<T, LOGSPACE, true>(c, m, key, first_subsequence, L, n_full, false, wave_steps);
+            run_batch<T, LOGSPACE, true>(c, m, key, first_subsequence, L, n_full, kCompactBelow, wave_steps);
             settle();
             j0 += kWave;
         }
@@ -233,7 +232,7 @@ __device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, co
             const uint32_t take = parked < kWave ? parked : kWave;
             const bool last = none_fresh && parked == take;   // nothing will join them: run to the end
             resume(take);
-            run_batch<T, LOGSPACE, false>(c, m, key, first_subsequence, L, n_full, last, wave_steps);
+            run_batch<T, LOGSPACE, false>(c, m, key, first_subsequence, L, n_full, last ? 0u : kCompactBelow, wave_steps);
             settle();
         }
         if (none_fresh) break;

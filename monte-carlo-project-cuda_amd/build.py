@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libmcamd.so")
 SOURCES = ["price_f64.hip", "price_f32.hip", "store.hip", "aux.hip", "nmc.hip", "capi.cpp", "group.cpp"]
 HEADERS = ["launch.hpp", "mc_device.hpp", "path_consts.hpp", "fast64.hpp", "tables64.inc", "tables64_consts.inc",
-           "price_impl.hpp"]
+           "price_impl.hpp", "nmc_compact.hpp"]
 ARCH = "gfx950"
 
 

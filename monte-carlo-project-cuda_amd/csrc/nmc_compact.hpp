@@ -17,7 +17,7 @@
 
 namespace mcamd {
 
-constexpr uint32_t kCompactBelow = 16;                       // hand over when this many lanes or fewer still run
+constexpr uint32_t kCompactBelow = 48;                       // hand over when this many lanes or fewer still run
 constexpr uint32_t kSurvivorCap = kWave + kCompactBelow;     // at most 63 parked + one hand-over
 
 // One wavefront's parked paths (structure of arrays: lane-consecutive slots, conflict-free).

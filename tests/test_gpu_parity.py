@@ -341,6 +341,43 @@ def test_log_space_nmc_matches_plain(ctx):
     assert torch.allclose(a, b, rtol=1e-11, atol=1e-12)
 
 
+@pytest.mark.parametrize("prec", [capi.F32, capi.F64])
+@pytest.mark.parametrize("flags", [0, capi.FLAG_LOG_SPACE])
+def test_nmc_lane_compaction_is_invisible_in_the_results(ctx, oracle, prec, flags):
+    # The wave-per-point kernel parks a wavefront's last live continuation paths in LDS and resumes them 64 at a time
+    # (csrc/nmc_compact.hpp).  A window that closes for most paths after a few steps while some run to maturity makes
+    # every mechanism fire (hand-over, resume of a full wavefront, drain of the rest); 1000 and 77 inner paths cover a
+    # partial last round.  Every point must still equal the oracle's per-path loop and the block-per-point kernel
+    # (which does not compact), the fused kernel must equal the two-launch route bit for bit, a repeat must be
+    # bit-identical, and the executed work must be below the uncompacted kernel's.
+    n_paths, n_steps = 24, 61      # odd remaining-step counts exercise the partial last Philox block
+    opt = capi.make_option(**BENCH, B=104.0, P1=2, P2=9, use_window=1)
+    outer = capi.make_sim(n_paths, n_steps, prec, seed=4242)
+    traj, cnt = dev(n_paths * n_steps, TORCH_T[prec]), dev(n_paths * n_steps, torch.int32)
+    ctx.simulate_trajectories(opt, outer, traj, cnt)
+    for n_inner in (1000, 77):
+        inner = capi.make_sim(n_paths, n_steps, prec, seed=99, n_paths_inner=n_inner, flags=flags)
+        w, w2, b, f = (dev(n_paths * n_steps, TORCH_T[prec]) for _ in range(4))
+        rw = ctx.nmc_inner(opt, inner, traj, cnt, w, capi.STEP_MAJOR, capi.NMC_WAVE_PER_POINT)
+        ctx.nmc_inner(opt, inner, traj, cnt, w2, capi.STEP_MAJOR, capi.NMC_WAVE_PER_POINT)
+        rb = ctx.nmc_inner(opt, inner, traj, cnt, b, capi.STEP_MAJOR, capi.NMC_BLOCK_PER_POINT)
+        t2, c2 = torch.empty_like(traj), torch.empty_like(cnt)
+        ctx.nmc_fused(opt, inner, 4242, t2, c2, f)
+        assert torch.equal(w, w2) and torch.equal(f, w) and torch.equal(t2, traj) and torch.equal(c2, cnt)
+        tol = dict(rtol=1e-11, atol=1e-12) if prec == capi.F64 else dict(rtol=2e-4, atol=2e-4)
+        assert torch.allclose(w, b, **tol)
+        if n_inner == 1000:
+            assert 0 < rw.work_steps < 0.8 * rb.work_steps
+        S, Cn, V = (a.view(n_steps, n_paths).cpu().numpy() for a in (traj, cnt, w))
+        p = oparams(oracle, opt, inner)
+        pts = [(s_, q) for s_ in (0, 1, 2, 5, 9, 17, 30, 58, 59, 60) for q in (0, 7, 23)]
+        want = np.array([oracle.nmc_point(p, prec, q * n_steps + s_, s_, float(S[s_, q]), int(Cn[s_, q])) for s_, q in pts])
+        got = np.array([V[s_, q] for s_, q in pts])
+        otol = dict(rtol=1e-11, atol=1e-10) if prec == capi.F64 else dict(rtol=5e-3, atol=5e-3)
+        assert np.allclose(got, want, **otol), np.abs(got - want).max()
+        assert (want > 0).any()
+
+
 # ---------------- opt-in variance reduction ----------------
 @pytest.mark.parametrize("prec", [capi.F32, capi.F64])
 @pytest.mark.parametrize("flags", [capi.FLAG_ANTITHETIC, capi.FLAG_CONTROL_VARIATE,
@@ -626,7 +663,7 @@ def test_randomised_nested_mc_vs_oracle(ctx, oracle):
     rng = np.random.default_rng(7)
     for case in range(24):
         prec = capi.F64 if case % 4 else capi.F32
-        n_paths, n_steps, n_inner = int(rng.integers(1, 9)), int(rng.integers(2, 24)), int(rng.choice([1, 5, 63, 64, 65, 130]))
+        n_paths, n_steps, n_inner = int(rng.integers(1, 9)), int(rng.integers(2, 24)), int(rng.choice([1, 5, 63, 64, 65, 130, 300, 1000]))
         B = 100.0 * float(rng.choice([0.0, 0.9, 1.0, 1.08, 3.0]))
         P1 = int(rng.integers(0, n_steps))
         P2 = int(rng.integers(P1, n_steps + 1))

@@ -455,7 +455,7 @@ def main(argv=None):
                 r_o = ctx.simulate_trajectories(nmc["opt"], sim_o, nmc["traj"], nmc["cnt"])
                 res = ctx.nmc_inner(nmc["opt"], sim_i, nmc["traj"], nmc["cnt"], nmc["out"], variant=nmc["variant"])
                 outer_ms = r_o.kernel_ms
-            nmc_runs.append((res.kernel_ms, outer_ms, res.work_steps))
+            nmc_runs.append((res.kernel_ms, outer_ms, res.work_steps, res.live_steps))
         if world > 1:
             s, s2, n = sharding.allreduce_stats(res.sum, res.sumsq, res.n, device=coll_device)
             fin = capi.finalize(s, s2, n, opt.r, opt.T)
@@ -521,7 +521,10 @@ def main(argv=None):
             line["config"]["strategy"] = args.nmc_strategy
             line["config"]["window"] = nmc["win"]
             line["inner_paths_per_s"] = inner_paths * args.steps / elapsed
+            live = sum(r[3] for r in nmc_runs) / len(nmc_runs)         # of those, lane-steps of paths whose window was open
             line["executed_inner_path_steps_per_pass"] = work
+            line["live_inner_path_steps_per_pass"] = live
+            line["lane_efficiency"] = live / work if work else None
             line["executed_inner_path_steps_per_s"] = work * args.steps / elapsed
             line["european_window_inner_path_steps"] = per_gpu * n_inner * (n_steps * (n_steps - 1) // 2)
             line["inner_kernel_ms"] = k_ms

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MCAMD_ABI_VERSION 3
+#define MCAMD_ABI_VERSION 4
 
 /* status codes */
 #define MCAMD_OK 0
@@ -138,6 +138,9 @@ typedef struct mcamd_result {
      * 64 lanes x the steps each wavefront ran (a wavefront leaves a point's step loop as soon as every lane's barrier
      * count is beyond P2, where the payoff can no longer be non-zero): the work figure for throughput / roofline */
     double work_steps;
+    /* of those, the lane-steps taken by paths whose window was still open (live_steps / work_steps = how full the
+     * wavefronts ran; equal to work_steps without a window) */
+    double live_steps;
 } mcamd_result;
 
 /* Device report: replaces getDeviceProperty (inc/tool.cuh:56-88) and the free/total memory

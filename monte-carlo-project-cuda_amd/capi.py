@@ -48,7 +48,7 @@ class Result(C.Structure):
                 ("std_err", C.c_double), ("ci_lo", C.c_double), ("ci_hi", C.c_double), ("kernel_ms", C.c_float),
                 ("total_ms", C.c_float), ("grid", C.c_uint32), ("block", C.c_uint32), ("sum_c", C.c_double),
                 ("sum_cc", C.c_double), ("sum_yc", C.c_double), ("cv_beta", C.c_double), ("cv_rho", C.c_double),
-                ("work_steps", C.c_double)]
+                ("work_steps", C.c_double), ("live_steps", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

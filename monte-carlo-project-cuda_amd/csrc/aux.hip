@@ -393,15 +393,22 @@ __global__ __launch_bounds__(kFinalBlock) void final_reduce_kernel(const double 
 hipError_t launch_final_reduce(const double *d_partials, uint32_t n_records, int record_doubles, double *d_out,
                                hipStream_t stream, double n_value)
 {
-    if (record_doubles == 5)
-        hipLaunchKernelGGL(final_reduce_kernel<5>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out,
-                           n_value);
-    else if (record_doubles == 3)
-        hipLaunchKernelGGL(final_reduce_kernel<3>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out,
-                           n_value);
-    else
+    switch (record_doubles) {
+    case 2:
         hipLaunchKernelGGL(final_reduce_kernel<2>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out,
                            n_value);
+        break;
+    case kNmcRecord:
+        hipLaunchKernelGGL(final_reduce_kernel<kNmcRecord>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records,
+                           d_out, n_value);
+        break;
+    case 5:
+        hipLaunchKernelGGL(final_reduce_kernel<5>, dim3(1), dim3(kFinalBlock), 0, stream, d_partials, n_records, d_out,
+                           n_value);
+        break;
+    default:
+        return hipErrorInvalidValue;   // a record width nobody instantiated must not fall through to another one
+    }
     return hipGetLastError();
 }
 

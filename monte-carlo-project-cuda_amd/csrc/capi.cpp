@@ -12,7 +12,7 @@
 #include <cstring>
 #include <string>
 
-static_assert(sizeof(mcamd_option) == 88 && sizeof(mcamd_sim) == 48 && sizeof(mcamd_result) == 120 &&
+static_assert(sizeof(mcamd_option) == 88 && sizeof(mcamd_sim) == 48 && sizeof(mcamd_result) == 128 &&
                   sizeof(mcamd_device_info) == 384,
               "C ABI struct layout changed: bump MCAMD_ABI_VERSION");
 
@@ -162,7 +162,10 @@ int finish(mcamd_ctx *ctx, uint32_t records, mcamd_result *res, int record_doubl
         res->sum_cc = ctx->h_out[3];
         res->sum_yc = ctx->h_out[4];
     }
-    if (record_doubles == mcamd::kNmcRecord) res->work_steps = 64.0 * ctx->h_out[2];  // wave-steps x 64 lanes
+    if (record_doubles == mcamd::kNmcRecord) {
+        res->work_steps = 64.0 * ctx->h_out[2];  // wave-steps x 64 lanes
+        res->live_steps = ctx->h_out[3];
+    }
     return MCAMD_OK;
 }
 

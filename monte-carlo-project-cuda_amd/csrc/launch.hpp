@@ -57,7 +57,7 @@ struct NmcJob {
     uint32_t compute_units;  // of the device the job runs on (sizes the persistent grid of the wave-per-point kernel)
 };
 // the nested-MC kernels write 3-double block records: {sum of point prices, sum of squares, wave-steps executed}
-constexpr int kNmcRecord = 3;
+constexpr int kNmcRecord = 4;
 uint32_t nmc_grid(const NmcJob &job, int variant);
 // d_queue: one zeroed 64-bit word (the wave-per-point kernel's task counter; the launcher zeroes it on `stream`)
 hipError_t launch_nmc_inner(const NmcJob &job, int layout, int variant, const void *d_prices, const int32_t *d_counts,

@@ -380,14 +380,15 @@ struct Sample {
     T pay;   // payoff (mean of the pair with ANTI)
     T ctrl;  // terminal price S_T (mean of the pair with ANTI); with WINDOW, the price where the loop stopped
     uint32_t steps_run;  // steps the wavefront executed (wave-uniform): n_sim unless the window let it stop early
+    uint32_t live_steps; // of steps_run x 64 lane-steps, those of lanes whose window was still open (wave-uniform, WINDOW only)
 };
 
-// true when no lane of the wavefront can still be paid: every barrier count is beyond P2
+// lanes of the wavefront that can still be paid (barrier count not beyond P2); 0: the window has closed for all
 template <bool ANTI>
-__device__ __forceinline__ bool window_closed(int32_t count, int32_t count2, int32_t P2)
+__device__ __forceinline__ uint32_t window_open_lanes(int32_t count, int32_t count2, int32_t P2)
 {
     const bool open = ANTI ? (count <= P2 || count2 <= P2) : (count <= P2);
-    return __builtin_amdgcn_ballot_w64(open) == 0;
+    return static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(open)));
 }
 
 // EARLY: leave the loop when the window has closed for the whole wavefront (off when the caller needs the
@@ -404,6 +405,9 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
     int32_t count2 = count;
     uint32_t steps_run = n_sim;
     bool rem_live = true;
+    // lanes entering the next block with an open window (EARLY only; every active lane at the start)
+    uint32_t open_lanes = EARLY ? static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(true))) : 0u;
+    uint32_t live_steps = 0;
     // LOGSPACE: WINDOW ? ln(St/S_start) so far : sum of the normals so far (the twin's sum is its negative)
     T acc = WINDOW ? log_start : T(0), acc2 = acc;
     if (LOGSPACE) {
@@ -424,10 +428,14 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
             nrm.fill(m, seed, subsequence, k);
 #pragma unroll
             for (int j = 0; j < NB; ++j) step(nrm.z[j]);
-            if (WINDOW && EARLY && window_closed<ANTI>(count, count2, c.P2)) {
-                steps_run = (k + 1) * NB;
-                rem_live = false;
-                break;
+            if (WINDOW && EARLY) {
+                live_steps += open_lanes * NB;
+                open_lanes = window_open_lanes<ANTI>(count, count2, c.P2);
+                if (open_lanes == 0) {
+                    steps_run = (k + 1) * NB;
+                    rem_live = false;
+                    break;
+                }
             }
         }
         if (rem && rem_live) {
@@ -456,10 +464,14 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
             ex.fill(m, c, seed, subsequence, k);
 #pragma unroll
             for (int j = 0; j < NB; ++j) step(ex.x[j]);
-            if (WINDOW && EARLY && window_closed<ANTI>(count, count2, c.P2)) {
-                steps_run = (k + 1) * NB;
-                rem_live = false;
-                break;
+            if (WINDOW && EARLY) {
+                live_steps += open_lanes * NB;
+                open_lanes = window_open_lanes<ANTI>(count, count2, c.P2);
+                if (open_lanes == 0) {
+                    steps_run = (k + 1) * NB;
+                    rem_live = false;
+                    break;
+                }
             }
         }
         if (rem && rem_live) {
@@ -484,6 +496,7 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
     }
     Sample<T> out;
     out.steps_run = steps_run;
+    out.live_steps = live_steps + ((rem && rem_live) ? open_lanes * rem : 0u);
     out.pay = payoff<T, WINDOW>(St, count, c);
     out.ctrl = St;
     if (ANTI) {
@@ -496,10 +509,12 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
 template <typename T, bool WINDOW, bool LOGSPACE>
 __device__ __forceinline__ T simulate_path(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &seed,
                                            uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
-                                           T log_start = T(0), uint32_t *steps_run = nullptr)
+                                           T log_start = T(0), uint32_t *steps_run = nullptr,
+                                           uint32_t *live_steps = nullptr)
 {
     const Sample<T> s = simulate_sample<T, WINDOW, LOGSPACE, false>(c, m, seed, subsequence, St, count, n_sim, log_start);
     if (steps_run) *steps_run += s.steps_run;
+    if (live_steps) *live_steps += s.live_steps;
     return s.pay;
 }
 

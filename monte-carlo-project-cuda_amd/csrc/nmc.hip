@@ -68,7 +68,8 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
     const StepConsts<T> c = resident(a.c);
     const int lane = threadIdx.x & (kWave - 1);
     __shared__ ParkedPaths<T, WINDOW> s_parked[kBlock / kWave];   // one buffer per wavefront (nmc_compact.hpp)
-    double rec[kNmcRecord] = {0.0, 0.0, 0.0};  // sum of point prices, sum of squares, wave-steps executed (lane 0)
+    // sum of point prices, sum of squares, wave-steps executed, lane-steps of paths with an open window (lane 0)
+    double rec[kNmcRecord] = {0.0, 0.0, 0.0, 0.0};
     for (;;) {
         unsigned long long first = 0;
         if (lane == 0) first = atomicAdd(queue, static_cast<unsigned long long>(kNmcChunk));
@@ -85,17 +86,19 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
             const uint32_t remaining = a.n_steps - (step + 1);
             const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
             double acc = 0.0;
-            uint32_t steps_run = 0;
+            uint32_t steps_run = 0, live_steps = 0;
             if constexpr (WINDOW) {
                 if (cnt0 <= c.P2) {
                     const T ls = (LOGSPACE || sizeof(T) == 8) ? log_ratio(St0, c.S_start) : T(0);
                     acc = point_sum_compacted<T, LOGSPACE>(c, m, key, point_id * a.n_inner, a.n_inner, St0, cnt0,
-                                                           remaining, ls, s_parked[threadIdx.x / kWave], steps_run);
+                                                           remaining, ls, s_parked[threadIdx.x / kWave], steps_run,
+                                                           live_steps);
                 }
             } else {
                 for (uint32_t j = lane; j < a.n_inner; j += kWave)
                     acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(
                         c, m, key, point_id * a.n_inner + j, St0, cnt0, remaining, T(0), &steps_run));
+                live_steps = a.n_inner * remaining;   // no window: every path runs every step
             }
             acc = wave_sum(acc);
             if (lane == 0) {
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
                 rec[0] += price;
                 rec[1] = __builtin_fma(price, price, rec[1]);
                 rec[2] += static_cast<double>(steps_run);   // lane 0 takes part in every pass over the inner paths
+                rec[3] += static_cast<double>(live_steps);
             }
         }
     }
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
     const MathCtx<T> m = MathCtx<T>::init();
     const PhiloxKeys key = PhiloxKeys::make(a.seed);
     const StepConsts<T> c = resident(a.c);
-    double psum = 0.0, psumsq = 0.0, pwork = 0.0;
+    double psum = 0.0, psumsq = 0.0, pwork = 0.0, plive = 0.0;
     for (uint64_t task = blockIdx.x; task < a.n_points; task += gridDim.x) {
         uint32_t step;
         uint64_t path;
@@ -129,30 +133,37 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
         const int32_t cnt0 = WINDOW ? a.counts[idx] : 0;
         const uint32_t remaining = a.n_steps - (step + 1);
         const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
-        double acc = 0.0, work = 0.0;
-        uint32_t steps_run = 0;
+        double acc = 0.0;
+        uint32_t steps_run = 0, live_steps = 0;
         if (!WINDOW || cnt0 <= c.P2) {
             const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
             for (uint32_t j = threadIdx.x; j < a.n_inner; j += kBlock)
-                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, key, point_id * a.n_inner + j,
-                                                                               St0, cnt0, remaining, ls, &steps_run));
+                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(
+                    c, m, key, point_id * a.n_inner + j, St0, cnt0, remaining, ls, &steps_run, &live_steps));
         }
-        // wave-steps: each wavefront's first lane runs every pass that wavefront makes
-        if ((threadIdx.x & (kWave - 1)) == 0) work = static_cast<double>(steps_run);
-        block_sum2<kBlock>(acc, work);
+        // wave-steps and live lane-steps: each wavefront's first lane runs every pass that wavefront makes
+        const bool first_lane = (threadIdx.x & (kWave - 1)) == 0;
+        double pt[3] = {acc, first_lane ? static_cast<double>(steps_run) : 0.0,
+                        first_lane ? static_cast<double>(WINDOW ? live_steps : 0u) : 0.0};
+        block_sumN<kBlock, 3>(pt);
+        acc = pt[0];
+        const double work = pt[1];
+        const double live = WINDOW ? pt[2] : static_cast<double>(a.n_inner) * remaining;
         if (threadIdx.x == 0) {
             const double price = acc * a.scale;
             a.out[idx] = static_cast<T>(price);
             psum += price;
             psumsq = __builtin_fma(price, price, psumsq);
             pwork += work;
+            plive += live;
         }
-        __syncthreads();  // block_sum2's LDS slots are reused by the next task
+        __syncthreads();  // block_sumN's LDS slots are reused by the next task
     }
     if (threadIdx.x == 0) {
         partials[kNmcRecord * static_cast<uint64_t>(blockIdx.x)] = psum;
         partials[kNmcRecord * static_cast<uint64_t>(blockIdx.x) + 1] = psumsq;
         partials[kNmcRecord * static_cast<uint64_t>(blockIdx.x) + 2] = pwork;
+        partials[kNmcRecord * static_cast<uint64_t>(blockIdx.x) + 3] = plive;
     }
 }
 
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
     const PhiloxKeys key = PhiloxKeys::make(a.seed);
 
     // ---- phase 2: inner stage over the owned points, one wavefront per point, long tasks first ----
-    double rec[kNmcRecord] = {0.0, 0.0, 0.0};
+    double rec[kNmcRecord] = {0.0, 0.0, 0.0, 0.0};
     const uint64_t n_tasks = n_owned * a.n_steps;
     // the workgroup's wavefronts pull its tasks from a counter in LDS (same reason as nmc_wave_kernel's queue)
     __shared__ unsigned int s_next;
@@ -227,17 +238,18 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
         const uint32_t remaining = a.n_steps - (step + 1);
         const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
         double acc = 0.0;
-        uint32_t steps_run = 0;
+        uint32_t steps_run = 0, live_steps = 0;
         if constexpr (WINDOW) {
             if (cnt0 <= c.P2) {
                 const T ls = (LOGSPACE || sizeof(T) == 8) ? log_ratio(St0, c.S_start) : T(0);
                 acc = point_sum_compacted<T, LOGSPACE>(c, m, key, point_id * a.n_inner, a.n_inner, St0, cnt0, remaining,
-                                                       ls, s_parked[wave], steps_run);
+                                                       ls, s_parked[wave], steps_run, live_steps);
             }
         } else {
             for (uint32_t j = lane; j < a.n_inner; j += kWave)
                 acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, key, point_id * a.n_inner + j, St0,
                                                                                cnt0, remaining, T(0), &steps_run));
+            live_steps = a.n_inner * remaining;
         }
         acc = wave_sum(acc);
         if (lane == 0) {
@@ -246,6 +258,7 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
             rec[0] += price;
             rec[1] = __builtin_fma(price, price, rec[1]);
             rec[2] += static_cast<double>(steps_run);
+            rec[3] += static_cast<double>(live_steps);
         }
     }
     block_sumN<kBlock, kNmcRecord>(rec);

@@ -127,7 +127,7 @@ struct BlockDraws {
 template <typename T, bool LOGSPACE, bool UNIFORM>
 __device__ __forceinline__ void run_batch(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
                                           uint64_t first_subsequence, InnerLane<T> &L, uint32_t n_full,
-                                          uint32_t live_limit, uint32_t &wave_steps)
+                                          uint32_t live_limit, uint32_t &wave_steps, uint32_t &live_steps)
 {
     constexpr int NB = Normals<T>::kPerBlock;
     const uint64_t subsequence = first_subsequence + L.j;
@@ -139,6 +139,7 @@ __device__ __forceinline__ void run_batch(const StepConsts<T> &c, const MathCtx<
         const uint32_t live = __builtin_amdgcn_readfirstlane(
             static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(run))));
         if (live <= live_limit) break;
+        live_steps += live * NB;
         if (run) {
             BlockDraws<T, LOGSPACE> d;
             d.fill(c, m, key, subsequence, UNIFORM ? kb : L.blk);
@@ -157,7 +158,7 @@ template <typename T, bool LOGSPACE>
 __device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
                                                       uint64_t first_subsequence, uint32_t n_inner, T St0, int32_t cnt0,
                                                       uint32_t remaining, T log_start, SurvivorBuf<T> &buf,
-                                                      uint32_t &wave_steps)
+                                                      uint32_t &wave_steps, uint32_t &live_steps)
 {
     constexpr int NB = Normals<T>::kPerBlock;
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -183,7 +184,12 @@ __device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, co
             const T St = LOGSPACE ? exp_of_logreturn(c.S_start, L.acc, m) : L.ps.value(m);
             sum += static_cast<double>(payoff<T, true>(St, L.count, c));
         }
-        if (rem != 0 && __builtin_amdgcn_ballot_w64(L.count <= c.P2 && L.blk >= n_full) != 0) wave_steps += rem;
+        if (rem != 0) {
+            const uint32_t finishing = static_cast<uint32_t>(
+                __builtin_popcountll(__builtin_amdgcn_ballot_w64(L.count <= c.P2 && L.blk >= n_full)));
+            if (finishing != 0) wave_steps += rem;
+            live_steps += finishing * rem;
+        }
         const bool waits = L.count <= c.P2 && L.blk < n_full;
         const uint64_t mask = __builtin_amdgcn_ballot_w64(waits);
         if (mask != 0) {
@@ -222,7 +228,7 @@ __device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, co
             L.j = j0 + lane;
             L.count = L.j < n_inner ? cnt0 : kNoPath;
             L.blk = 0;
-            run_batch<T, LOGSPACE, true>(c, m, key, first_subsequence, L, n_full, kCompactBelow, wave_steps);
+            run_batch<T, LOGSPACE, true>(c, m, key, first_subsequence, L, n_full, kCompactBelow, wave_steps, live_steps);
             settle();
             j0 += kWave;
         }
@@ -232,7 +238,7 @@ __device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, co
             const uint32_t take = parked < kWave ? parked : kWave;
             const bool last = none_fresh && parked == take;   // nothing will join them: run to the end
             resume(take);
-            run_batch<T, LOGSPACE, false>(c, m, key, first_subsequence, L, n_full, last ? 0u : kCompactBelow, wave_steps);
+            run_batch<T, LOGSPACE, false>(c, m, key, first_subsequence, L, n_full, last ? 0u : kCompactBelow, wave_steps, live_steps);
             settle();
         }
         if (none_fresh) break;

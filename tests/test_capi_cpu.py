@@ -29,7 +29,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mcamd_abi_version() == 3
+    assert lib.mcamd_abi_version() == 4
 
 
 def test_slot_counts_describe_the_built_library(lib):
@@ -45,7 +45,7 @@ def test_slot_counts_describe_the_built_library(lib):
 
 def test_struct_layout_is_the_documented_abi():
     assert C.sizeof(capi.Option) == 88 and C.sizeof(capi.Sim) == 48
-    assert C.sizeof(capi.Result) == 120 and C.sizeof(capi.DeviceInfo) == 384
+    assert C.sizeof(capi.Result) == 128 and C.sizeof(capi.DeviceInfo) == 384
 
 
 def test_closed_form_matches_reference_golden_bitwise(lib, golden):

@@ -366,8 +366,13 @@ def test_nmc_lane_compaction_is_invisible_in_the_results(ctx, oracle, prec, flag
         assert torch.equal(w, w2) and torch.equal(f, w) and torch.equal(t2, traj) and torch.equal(c2, cnt)
         tol = dict(rtol=1e-11, atol=1e-12) if prec == capi.F64 else dict(rtol=2e-4, atol=2e-4)
         assert torch.allclose(w, b, **tol)
+        assert 0 < rw.live_steps <= rw.work_steps and 0 < rb.live_steps <= rb.work_steps
         if n_inner == 1000:
             assert 0 < rw.work_steps < 0.8 * rb.work_steps
+            # both kernels count the same live paths (to within the block in which a path's window closes); the
+            # compacting kernel spends far fewer lane-steps on them
+            assert abs(rw.live_steps - rb.live_steps) < 0.02 * rb.live_steps
+            assert rw.live_steps / rw.work_steps > 1.5 * rb.live_steps / rb.work_steps
         S, Cn, V = (a.view(n_steps, n_paths).cpu().numpy() for a in (traj, cnt, w))
         p = oparams(oracle, opt, inner)
         pts = [(s_, q) for s_ in (0, 1, 2, 5, 9, 17, 30, 58, 59, 60) for q in (0, 7, 23)]
@@ -605,6 +610,10 @@ def test_nmc_variants_agree_and_european_window(ctx):
     rb = ctx.nmc_inner(opt, inner, traj, cnt, b, capi.STEP_MAJOR, capi.NMC_BLOCK_PER_POINT)
     assert torch.allclose(a, b, rtol=1e-12, atol=1e-12) and math.isclose(ra.sum, rb.sum, rel_tol=1e-12)
     assert (cnt == 0).all()
+    # no path ever leaves: the live lane-steps are the European-window count, and the executed ones are that rounded
+    # up to whole wavefronts and whole Philox blocks
+    european = n_paths * n_inner * (n_steps * (n_steps - 1) // 2)
+    assert ra.live_steps == european == rb.live_steps and european <= ra.work_steps < 1.2 * european
     # inner price of point (s, q) estimates e^{-rT} E[(S_T-K)+ | S_s]: compare with closed form * growth, loosely
     S = traj.view(n_steps, n_paths)[5].cpu().numpy()
     tau = 1.0 - 6 / 12

@@ -30,10 +30,12 @@ def main():
     res = {"outer_kernel_ms": ro.kernel_ms}
     for name, variant in (("wave", capi.NMC_WAVE_PER_POINT), ("block", capi.NMC_BLOCK_PER_POINT)):
         r = ctx.nmc_inner(opt, inner, traj, cnt, out, variant=variant)
-        res[name] = {"kernel_ms": r.kernel_ms, "work_steps": r.work_steps, "mean_point_price": r.price,
+        res[name] = {"kernel_ms": r.kernel_ms, "work_steps": r.work_steps, "live_steps": r.live_steps,
+                     "lane_efficiency": r.live_steps / r.work_steps, "mean_point_price": r.price,
                      "lane_steps_per_s": r.work_steps / (r.kernel_ms / 1e3)}
     r = ctx.nmc_fused(opt, inner, 1234, traj, cnt, out)
-    res["fused"] = {"kernel_ms": r.kernel_ms, "work_steps": r.work_steps, "mean_point_price": r.price,
+    res["fused"] = {"kernel_ms": r.kernel_ms, "work_steps": r.work_steps, "live_steps": r.live_steps,
+                    "lane_efficiency": r.live_steps / r.work_steps, "mean_point_price": r.price,
                     "lane_steps_per_s": r.work_steps / (r.kernel_ms / 1e3)}
     ctx.close()
     print(json.dumps(res))

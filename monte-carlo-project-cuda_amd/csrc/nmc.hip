@@ -57,7 +57,80 @@ __device__ __forceinline__ uint64_t point_index(const NmcArgs<T> &a, uint64_t ta
     return LAYOUT == MCAMD_STEP_MAJOR ? task : path * a.n_steps + step;
 }
 
-constexpr uint32_t kNmcChunk = 4;  // tasks per dequeue: same step, adjacent paths
+// A task of the wave-per-point and fused kernels is a GROUP: one step of kPool adjacent outer paths (the last group of
+// a step may be short).  With a window the group's continuation paths are one pool for the lane compaction of
+// nmc_compact.hpp; without one its points are simply priced one after the other.
+template <typename T, int LAYOUT>
+__device__ __forceinline__ uint64_t stored_index(const NmcArgs<T> &a, uint32_t step, uint64_t path)
+{
+    return LAYOUT == MCAMD_STEP_MAJOR ? static_cast<uint64_t>(step) * a.n_local + path : path * a.n_steps + step;
+}
+
+// Prices the points (step, path0 .. path0 + n_pts - 1) with one wavefront and adds them to the wavefront's record
+// (lane 0): rec = {sum of point prices, sum of squares, wave-steps executed, lane-steps of paths with an open window}.
+template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE>
+__device__ __forceinline__ void price_group(const NmcArgs<T> &a, const StepConsts<T> &c, const MathCtx<T> &m,
+                                            const PhiloxKeys &key, const T *prices, const int32_t *counts, uint32_t step,
+                                            uint64_t path0, uint32_t n_pts, ParkedPaths<T, WINDOW> &parked,
+                                            double (&rec)[kNmcRecord])
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t remaining = a.n_steps - (step + 1);
+    if constexpr (WINDOW) {
+        if (lane < kPool) {   // lane s describes point s of the group
+            const bool present = lane < n_pts;
+            const uint64_t idx = stored_index<T, LAYOUT>(a, step, path0 + (present ? lane : 0u));
+            const T St0 = prices[idx];
+            int32_t cnt0 = counts[idx];
+            // a point whose count is already beyond P2 can never pay (inc/nmc.cuh:53,330): no path of it is started
+            if (!present || cnt0 > c.P2) cnt0 = kNoPath;
+            parked.pt_St0[lane] = St0;
+            parked.pt_cnt0[lane] = cnt0;
+            parked.pt_log_start[lane] =
+                (cnt0 != kNoPath && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
+            parked.pt_subsequence[lane] = ((a.path_offset + path0 + lane) * a.n_steps + step) * a.n_inner;
+            parked.pt_sum[lane] = 0.0;
+        }
+        wave_lds_fence();
+        uint32_t steps_run = 0, live_steps = 0;
+        group_sums_compacted<T, LOGSPACE>(c, m, key, a.n_inner, remaining, parked, steps_run, live_steps);
+        wave_lds_fence();
+#pragma unroll
+        for (uint32_t s = 0; s < kPool; ++s) {
+            if (lane == 0 && s < n_pts) {
+                const double price = parked.pt_sum[s] * a.scale;
+                a.out[stored_index<T, LAYOUT>(a, step, path0 + s)] = static_cast<T>(price);
+                rec[0] += price;
+                rec[1] = __builtin_fma(price, price, rec[1]);
+            }
+        }
+        if (lane == 0) {
+            rec[2] += static_cast<double>(steps_run);
+            rec[3] += static_cast<double>(live_steps);
+        }
+        wave_lds_fence();   // the next group's description must not overtake this group's last reads
+    } else {
+        for (uint32_t s = 0; s < n_pts; ++s) {
+            const uint64_t idx = stored_index<T, LAYOUT>(a, step, path0 + s);
+            const T St0 = prices[idx];
+            const uint64_t point_id = (a.path_offset + path0 + s) * a.n_steps + step;
+            double acc = 0.0;
+            uint32_t steps_run = 0;
+            for (uint32_t j = lane; j < a.n_inner; j += kWave)
+                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, key, point_id * a.n_inner + j, St0, 0,
+                                                                               remaining, T(0), &steps_run));
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                const double price = acc * a.scale;
+                a.out[idx] = static_cast<T>(price);
+                rec[0] += price;
+                rec[1] = __builtin_fma(price, price, rec[1]);
+                rec[2] += static_cast<double>(steps_run);   // lane 0 takes part in every pass over the inner paths
+                rec[3] += static_cast<double>(a.n_inner) * remaining;   // no window: every path runs every step
+            }
+        }
+    }
+}
 
 template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE>
 __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *__restrict__ partials,
@@ -68,48 +141,20 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
     const StepConsts<T> c = resident(a.c);
     const int lane = threadIdx.x & (kWave - 1);
     __shared__ ParkedPaths<T, WINDOW> s_parked[kBlock / kWave];   // one buffer per wavefront (nmc_compact.hpp)
-    // sum of point prices, sum of squares, wave-steps executed, lane-steps of paths with an open window (lane 0)
     double rec[kNmcRecord] = {0.0, 0.0, 0.0, 0.0};
+    const uint64_t groups_per_step = (a.n_local + kPool - 1) / kPool;
+    const uint64_t n_groups = groups_per_step * a.n_steps;   // step-major: the long tasks come first
     for (;;) {
         unsigned long long first = 0;
-        if (lane == 0) first = atomicAdd(queue, static_cast<unsigned long long>(kNmcChunk));
-        const uint64_t base = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(first >> 32))) << 32) |
-                              __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(first));
-        if (base >= a.n_points) break;
-        const uint64_t end = base + kNmcChunk < a.n_points ? base + kNmcChunk : a.n_points;
-        for (uint64_t task = base; task < end; ++task) {
-            uint32_t step;
-            uint64_t path;
-            const uint64_t idx = point_index<T, WINDOW, LAYOUT>(a, task, step, path);
-            const T St0 = a.prices[idx];
-            const int32_t cnt0 = WINDOW ? a.counts[idx] : 0;
-            const uint32_t remaining = a.n_steps - (step + 1);
-            const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
-            double acc = 0.0;
-            uint32_t steps_run = 0, live_steps = 0;
-            if constexpr (WINDOW) {
-                if (cnt0 <= c.P2) {
-                    const T ls = (LOGSPACE || sizeof(T) == 8) ? log_ratio(St0, c.S_start) : T(0);
-                    acc = point_sum_compacted<T, LOGSPACE>(c, m, key, point_id * a.n_inner, a.n_inner, St0, cnt0,
-                                                           remaining, ls, s_parked[threadIdx.x / kWave], steps_run,
-                                                           live_steps);
-                }
-            } else {
-                for (uint32_t j = lane; j < a.n_inner; j += kWave)
-                    acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(
-                        c, m, key, point_id * a.n_inner + j, St0, cnt0, remaining, T(0), &steps_run));
-                live_steps = a.n_inner * remaining;   // no window: every path runs every step
-            }
-            acc = wave_sum(acc);
-            if (lane == 0) {
-                const double price = acc * a.scale;
-                a.out[idx] = static_cast<T>(price);
-                rec[0] += price;
-                rec[1] = __builtin_fma(price, price, rec[1]);
-                rec[2] += static_cast<double>(steps_run);   // lane 0 takes part in every pass over the inner paths
-                rec[3] += static_cast<double>(live_steps);
-            }
-        }
+        if (lane == 0) first = atomicAdd(queue, 1ull);
+        const uint64_t g = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(first >> 32))) << 32) |
+                           __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(first));
+        if (g >= n_groups) break;
+        const uint32_t step = static_cast<uint32_t>(g / groups_per_step);
+        const uint64_t path0 = (g - static_cast<uint64_t>(step) * groups_per_step) * kPool;
+        const uint32_t n_pts = a.n_local - path0 < kPool ? static_cast<uint32_t>(a.n_local - path0) : kPool;
+        price_group<T, WINDOW, LAYOUT, LOGSPACE>(a, c, m, key, a.prices, a.counts, step, path0, n_pts,
+                                                 s_parked[threadIdx.x / kWave], rec);
     }
     block_sumN<kBlock, kNmcRecord>(rec);
     if (threadIdx.x == 0) {
@@ -186,14 +231,16 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const StepConsts<T> c = resident(a.c);
-    // owned paths: blockIdx.x, blockIdx.x + G, ...
-    const uint64_t n_owned = a.n_local > blockIdx.x ? (a.n_local - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    // owned path groups (kPool adjacent paths each, the groups of nmc_wave_kernel): blockIdx.x, blockIdx.x + G, ...
+    const uint64_t groups_per_step = (a.n_local + kPool - 1) / kPool;
+    const uint64_t n_owned = groups_per_step > blockIdx.x ? (groups_per_step - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
 
     // ---- phase 1: outer trajectories of the owned paths (inc/nmc.cuh:144-202) ----
     {
     const PhiloxKeys outer_key = PhiloxKeys::make(outer_seed);   // its 20 registers are free again after this phase
-    for (uint64_t i = threadIdx.x; i < n_owned; i += kBlock) {
-        const uint64_t path = blockIdx.x + i * gridDim.x;
+    for (uint64_t i = threadIdx.x; i < n_owned * kPool; i += kBlock) {
+        const uint64_t path = (blockIdx.x + (i / kPool) * gridDim.x) * kPool + i % kPool;
+        if (path >= a.n_local) continue;   // the last group of the row may be short
         PathState<T> ps = PathState<T>::start(c.S_start);
         int32_t cnt = c.Ik;
         Exponents<T> ex;
@@ -205,8 +252,7 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
             ps.step(x, m);
             const T St = ps.value(m);
             if (WINDOW) cnt += (c.B > St) ? 1 : 0;
-            const uint64_t idx = LAYOUT == MCAMD_STEP_MAJOR ? static_cast<uint64_t>(step) * a.n_local + path
-                                                            : path * a.n_steps + step;
+            const uint64_t idx = stored_index<T, LAYOUT>(a, step, path);
             prices[idx] = St;
             if (WINDOW) counts[idx] = cnt;
         }
@@ -215,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
     __syncthreads();  // workgroup-scope release/acquire: this workgroup reads only what it wrote
     const PhiloxKeys key = PhiloxKeys::make(a.seed);
 
-    // ---- phase 2: inner stage over the owned points, one wavefront per point, long tasks first ----
+    // ---- phase 2: inner stage over the owned groups, one wavefront per group, long tasks first ----
     double rec[kNmcRecord] = {0.0, 0.0, 0.0, 0.0};
     const uint64_t n_tasks = n_owned * a.n_steps;
     // the workgroup's wavefronts pull its tasks from a counter in LDS (same reason as nmc_wave_kernel's queue)
@@ -223,43 +269,15 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
     __shared__ ParkedPaths<T, WINDOW> s_parked[kWaves];   // one buffer per wavefront (nmc_compact.hpp)
     if (threadIdx.x == 0) s_next = 0;
     __syncthreads();
-    (void)wave;
     for (;;) {
         unsigned int mine = 0;
         if (lane == 0) mine = atomicAdd(&s_next, 1u);
         const uint64_t task = __builtin_amdgcn_readfirstlane(mine);
         if (task >= n_tasks) break;
         const uint32_t step = static_cast<uint32_t>(task / n_owned);
-        const uint64_t path = blockIdx.x + (task - static_cast<uint64_t>(step) * n_owned) * gridDim.x;
-        const uint64_t idx = LAYOUT == MCAMD_STEP_MAJOR ? static_cast<uint64_t>(step) * a.n_local + path
-                                                        : path * a.n_steps + step;
-        const T St0 = prices[idx];
-        const int32_t cnt0 = WINDOW ? counts[idx] : 0;
-        const uint32_t remaining = a.n_steps - (step + 1);
-        const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
-        double acc = 0.0;
-        uint32_t steps_run = 0, live_steps = 0;
-        if constexpr (WINDOW) {
-            if (cnt0 <= c.P2) {
-                const T ls = (LOGSPACE || sizeof(T) == 8) ? log_ratio(St0, c.S_start) : T(0);
-                acc = point_sum_compacted<T, LOGSPACE>(c, m, key, point_id * a.n_inner, a.n_inner, St0, cnt0, remaining,
-                                                       ls, s_parked[wave], steps_run, live_steps);
-            }
-        } else {
-            for (uint32_t j = lane; j < a.n_inner; j += kWave)
-                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, key, point_id * a.n_inner + j, St0,
-                                                                               cnt0, remaining, T(0), &steps_run));
-            live_steps = a.n_inner * remaining;
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            const double price = acc * a.scale;
-            a.out[idx] = static_cast<T>(price);
-            rec[0] += price;
-            rec[1] = __builtin_fma(price, price, rec[1]);
-            rec[2] += static_cast<double>(steps_run);
-            rec[3] += static_cast<double>(live_steps);
-        }
+        const uint64_t path0 = (blockIdx.x + (task - static_cast<uint64_t>(step) * n_owned) * gridDim.x) * kPool;
+        const uint32_t n_pts = a.n_local - path0 < kPool ? static_cast<uint32_t>(a.n_local - path0) : kPool;
+        price_group<T, WINDOW, LAYOUT, LOGSPACE>(a, c, m, key, prices, counts, step, path0, n_pts, s_parked[wave], rec);
     }
     block_sumN<kBlock, kNmcRecord>(rec);
     if (threadIdx.x == 0) {
@@ -270,9 +288,10 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
 
 uint32_t nmc_fused_grid(const NmcJob &job)
 {
-    // a workgroup owns whole outer paths; many small workgroups (two paths each at BASELINE configs[3]) keep the
-    // end of the launch short, since a workgroup's work depends on when ITS paths' windows close
-    const uint64_t want = job.path.n_local < 32768 ? job.path.n_local : 32768;
+    // a workgroup owns whole groups of kPool outer paths; many small workgroups (one group each at BASELINE
+    // configs[3]) keep the end of the launch short, since a workgroup's work depends on when ITS paths' windows close
+    const uint64_t groups = (job.path.n_local + kPool - 1) / kPool;
+    const uint64_t want = groups < 32768 ? groups : 32768;
     return static_cast<uint32_t>(want < 1 ? 1 : want);
 }
 
@@ -293,8 +312,9 @@ uint32_t nmc_grid(const NmcJob &job, int variant)
 {
     if (variant == MCAMD_NMC_BLOCK_PER_POINT) return clamp_grid(job.n_points);
     // wave per point: persistent grid, 8 workgroups per CU (all that can be resident), tasks pulled from a queue
-    const uint64_t per_block = static_cast<uint64_t>(kBlock / kWave) * kNmcChunk;
-    const uint64_t need = (job.n_points + per_block - 1) / per_block;
+    const uint64_t groups = (job.path.n_local + kPool - 1) / kPool * job.path.n_steps;   // the kernel's tasks
+    const uint64_t per_block = static_cast<uint64_t>(kBlock / kWave);
+    const uint64_t need = (groups + per_block - 1) / per_block;
     const uint64_t resident = static_cast<uint64_t>(job.compute_units ? job.compute_units : 256) * 8;
     return static_cast<uint32_t>(need < 1 ? 1 : (need < resident ? need : resident));
 }

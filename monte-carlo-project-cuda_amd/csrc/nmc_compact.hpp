@@ -10,15 +10,21 @@
 // 64 parked paths have gathered they are resumed together, full width, under the same rule.  Philox is
 // counter-based, so a resumed path continues its own stream at its own block whatever lane it lands in:
 // every path's payoff is bit-identical to the uncompacted loop, only the summation order of the point's mean
-// changes (deterministically: the schedule depends on the point alone, not on timing).
+// changes (deterministically: the schedule depends on the points alone, not on timing).
+// The pool a wavefront draws fresh paths from is a GROUP of kPool points — the same step of kPool adjacent outer
+// paths, so all their continuation paths have the same number of steps to go — which leaves fewer half-empty
+// batches at the end than one point alone would (the last batch of a pool runs to completion whatever its width).
 #pragma once
 
 #include "mc_device.hpp"
 
 namespace mcamd {
 
+constexpr uint32_t kPool = 4;                                // points per group (a group is one task of the kernels)
 constexpr uint32_t kCompactBelow = 48;                       // hand over when this many lanes or fewer still run
 constexpr uint32_t kSurvivorCap = kWave + kCompactBelow;     // at most 63 parked + one hand-over
+
+constexpr int32_t kNoPath = 0x7fffffff;
 
 // One wavefront's parked paths (structure of arrays: lane-consecutive slots, conflict-free).
 template <typename T>
@@ -27,8 +33,15 @@ struct SurvivorBuf {
     T b[kSurvivorCap];             // fp64 product form: kq (barrier accumulator);  unused otherwise
     int32_t k[kSurvivorCap];       // fp64 product form: integer exponent;  unused otherwise
     int32_t count[kSurvivorCap];
-    uint32_t j[kSurvivorCap];      // index of the path among the point's continuation paths
+    uint32_t j[kSurvivorCap];      // index of the path among its point's continuation paths
     uint32_t blk[kSurvivorCap];    // next Philox block of its stream
+    uint32_t slot[kSurvivorCap];   // which point of the group it belongs to
+    // the group's points (written by the wavefront when it takes the group)
+    uint64_t pt_subsequence[kPool];   // Philox subsequence of the point's continuation path 0
+    T pt_St0[kPool];                  // stored outer price
+    T pt_log_start[kPool];            // ln(St0 / S_start) in exponent units (0 where unused)
+    int32_t pt_cnt0[kPool];           // stored outer count; kNoPath marks a point that is absent or already closed
+    double pt_sum[kPool];             // running sum of the point's payoffs (lane 0 adds each batch's total)
 };
 
 // What a kernel declares in LDS per wavefront: the buffer when there is a window, nothing otherwise.
@@ -43,9 +56,9 @@ struct InnerLane {
     PathState<T> ps;   // product form
     T acc;             // log-space form
     int32_t count;     // barrier count; kNoPath in a lane that holds no path (so "count <= P2" means: a live path)
-    uint32_t j, blk;
+    uint32_t blk, slot;
+    uint64_t subsequence;   // Philox subsequence of the path (its point's first one + the path's index)
 };
-constexpr int32_t kNoPath = 0x7fffffff;
 
 __device__ __forceinline__ void park(SurvivorBuf<float> &buf, uint32_t slot, const InnerLane<float> &L, bool logspace)
 {
@@ -76,6 +89,10 @@ __device__ __forceinline__ void unpark(const SurvivorBuf<double> &buf, uint32_t 
         L.ps.a.k = buf.k[slot];
     }
 }
+
+// The start price of a resumed path (fp64 keeps it beside the factored product; fp32 carries the price itself).
+__device__ __forceinline__ void set_start_price(PathState<float> &, float) {}
+__device__ __forceinline__ void set_start_price(PathState<double> &ps, double St0) { ps.S0 = St0; }
 
 // LDS traffic between lanes of one wavefront: the hardware serves a wavefront's LDS instructions in order; this
 // keeps the compiler from moving them across the hand-over.
@@ -126,11 +143,11 @@ struct BlockDraws {
 // stays scalar and the first Philox round keeps its scalar half.
 template <typename T, bool LOGSPACE, bool UNIFORM>
 __device__ __forceinline__ void run_batch(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
-                                          uint64_t first_subsequence, InnerLane<T> &L, uint32_t n_full,
-                                          uint32_t live_limit, uint32_t &wave_steps, uint32_t &live_steps)
+                                          InnerLane<T> &L, uint32_t n_full, uint32_t live_limit, uint32_t &wave_steps,
+                                          uint32_t &live_steps)
 {
     constexpr int NB = Normals<T>::kPerBlock;
-    const uint64_t subsequence = first_subsequence + L.j;
+    const uint64_t subsequence = L.subsequence;
     uint32_t kb = 0;   // blocks this call ran (wave-uniform); UNIFORM: also the block index of every running lane
     for (; !UNIFORM || kb < n_full; ++kb) {
         // liveness is read off the count every time (one compare straight into a lane mask) rather than carried
@@ -152,42 +169,51 @@ __device__ __forceinline__ void run_batch(const StepConsts<T> &c, const MathCtx<
     wave_steps += static_cast<uint32_t>(NB) * static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(kb));
 }
 
-// Sum of the window payoffs of the point's n_inner continuation paths (this lane's share: the caller adds the
-// lanes up).  Streams: path j uses Philox subsequence first_subsequence + j, as the uncompacted loop does.
+// Sums of the window payoffs of the continuation paths of a group's points, into buf.pt_sum[s] for point s (the
+// caller zeroes them).  The points are described in buf.pt_* (pt_cnt0 = kNoPath: skip); all have
+// `remaining` steps to go and n_inner paths; path j of point s uses Philox subsequence pt_subsequence[s] + j, as the
+// uncompacted loop does.
 template <typename T, bool LOGSPACE>
-__device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
-                                                      uint64_t first_subsequence, uint32_t n_inner, T St0, int32_t cnt0,
-                                                      uint32_t remaining, T log_start, SurvivorBuf<T> &buf,
-                                                      uint32_t &wave_steps, uint32_t &live_steps)
+__device__ __forceinline__ void group_sums_compacted(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
+                                                     uint32_t n_inner, uint32_t remaining, SurvivorBuf<T> &buf,
+                                                     uint32_t &wave_steps, uint32_t &live_steps)
 {
     constexpr int NB = Normals<T>::kPerBlock;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t n_full = remaining / NB;
     const uint32_t rem = remaining - n_full * NB;
-    double sum = 0.0;
     uint32_t parked = 0;   // wave-uniform
 
     InnerLane<T> L;
-    L.ps = PathState<T>::start(St0);
+    L.ps = PathState<T>::start(T(0));
+    L.slot = 0;
 
     // finished paths take the steps of the partial last block (rem of them) and pay; paths still running wait in
     // the buffer
     auto settle = [&]() {
-        if (L.count <= c.P2 && L.blk >= n_full) {
+        double pay = 0.0;
+        const bool done = L.count <= c.P2 && L.blk >= n_full;
+        const uint32_t finishing = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(done)));
+        if (done) {
             if (rem != 0) {
                 BlockDraws<T, LOGSPACE> d;
-                d.fill(c, m, key, first_subsequence + L.j, n_full);
+                d.fill(c, m, key, L.subsequence, n_full);
 #pragma unroll
                 for (int s = 0; s < NB - 1; ++s)
                     if (static_cast<uint32_t>(s) < rem) inner_step<T, LOGSPACE>(c, m, L, d.v[s]);
             }
             const T St = LOGSPACE ? exp_of_logreturn(c.S_start, L.acc, m) : L.ps.value(m);
-            sum += static_cast<double>(payoff<T, true>(St, L.count, c));
+            pay = static_cast<double>(payoff<T, true>(St, L.count, c));
         }
-        if (rem != 0) {
-            const uint32_t finishing = static_cast<uint32_t>(
-                __builtin_popcountll(__builtin_amdgcn_ballot_w64(L.count <= c.P2 && L.blk >= n_full)));
-            if (finishing != 0) wave_steps += rem;
+        if (finishing != 0) {
+            // the batch's payoffs, point by point, onto the points' running sums: a few dozen instructions in the
+            // batches where a path reaches maturity, against eight vector registers for per-lane sums all the time
+#pragma unroll
+            for (uint32_t s = 0; s < kPool; ++s) {
+                const double total = wave_sum(L.slot == s ? pay : 0.0);
+                if (lane == 0) buf.pt_sum[s] += total;
+            }
+            wave_steps += rem;
             live_steps += finishing * rem;
         }
         const bool waits = L.count <= c.P2 && L.blk < n_full;
@@ -196,11 +222,12 @@ __device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, co
             const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
             if (waits) {
-                const uint32_t slot = parked + below;
-                park(buf, slot, L, LOGSPACE);
-                buf.count[slot] = L.count;
-                buf.j[slot] = L.j;
-                buf.blk[slot] = L.blk;
+                const uint32_t at = parked + below;
+                park(buf, at, L, LOGSPACE);
+                buf.count[at] = L.count;
+                buf.j[at] = static_cast<uint32_t>(L.subsequence - buf.pt_subsequence[L.slot]);
+                buf.blk[at] = L.blk;
+                buf.slot[at] = L.slot;
             }
             parked += static_cast<uint32_t>(__builtin_popcountll(mask));
             wave_lds_fence();
@@ -211,39 +238,49 @@ __device__ __forceinline__ double point_sum_compacted(const StepConsts<T> &c, co
         parked -= take;
         L.count = kNoPath;
         if (lane < take) {
-            const uint32_t slot = parked + lane;
-            unpark(buf, slot, L, LOGSPACE);
-            L.count = buf.count[slot];
-            L.j = buf.j[slot];
-            L.blk = buf.blk[slot];
+            const uint32_t at = parked + lane;
+            unpark(buf, at, L, LOGSPACE);
+            L.count = buf.count[at];
+            L.blk = buf.blk[at];
+            L.slot = buf.slot[at];
+            L.subsequence = buf.pt_subsequence[L.slot] + buf.j[at];
+            set_start_price(L.ps, buf.pt_St0[L.slot]);
         }
         wave_lds_fence();
     };
 
-    for (uint32_t j0 = 0;;) {
-        if (j0 < n_inner) {   // the next 64 fresh paths
+    uint32_t slot = 0, j0 = 0;   // the next fresh paths: j0.. of point `slot`
+    for (;;) {
+        while (slot < kPool && __builtin_amdgcn_readfirstlane(buf.pt_cnt0[slot]) == kNoPath) ++slot;   // absent or closed
+        if (slot < kPool) {   // the next 64 fresh paths
+            const T St0 = buf.pt_St0[slot], log_start = buf.pt_log_start[slot];
             L.ps = PathState<T>::start(St0);
             if (!LOGSPACE) L.ps.arm_barrier(c.logB - log_start);   // ln(B / St0) = ln(B / S_start) - ln(St0 / S_start)
             L.acc = log_start;
-            L.j = j0 + lane;
-            L.count = L.j < n_inner ? cnt0 : kNoPath;
+            L.slot = slot;
+            L.subsequence = buf.pt_subsequence[slot] + (j0 + lane);
+            L.count = j0 + lane < n_inner ? buf.pt_cnt0[slot] : kNoPath;
             L.blk = 0;
-            run_batch<T, LOGSPACE, true>(c, m, key, first_subsequence, L, n_full, kCompactBelow, wave_steps, live_steps);
+            run_batch<T, LOGSPACE, true>(c, m, key, L, n_full, kCompactBelow, wave_steps, live_steps);
             settle();
             j0 += kWave;
+            if (j0 >= n_inner) {
+                j0 = 0;
+                ++slot;
+            }
+            while (slot < kPool && __builtin_amdgcn_readfirstlane(buf.pt_cnt0[slot]) == kNoPath) ++slot;
         }
-        const bool none_fresh = j0 >= n_inner;
+        const bool none_fresh = slot >= kPool;
         // a full wavefront of parked paths — or, when no fresh ones are left, whatever is parked
         while (parked >= kWave || (none_fresh && parked != 0)) {
             const uint32_t take = parked < kWave ? parked : kWave;
             const bool last = none_fresh && parked == take;   // nothing will join them: run to the end
             resume(take);
-            run_batch<T, LOGSPACE, false>(c, m, key, first_subsequence, L, n_full, last ? 0u : kCompactBelow, wave_steps, live_steps);
+            run_batch<T, LOGSPACE, false>(c, m, key, L, n_full, last ? 0u : kCompactBelow, wave_steps, live_steps);
             settle();
         }
         if (none_fresh) break;
     }
-    return sum;
 }
 
 }  // namespace mcamd

@@ -20,7 +20,7 @@
 
 namespace mcamd {
 
-constexpr uint32_t kPool = 4;                                // points per group (a group is one task of the kernels)
+constexpr uint32_t kPool = 8;                                 // points per group (a group is one task of the kernels)
 constexpr uint32_t kCompactBelow = 48;                       // hand over when this many lanes or fewer still run
 constexpr uint32_t kSurvivorCap = kWave + kCompactBelow;     // at most 63 parked + one hand-over
 

@@ -189,8 +189,8 @@ __device__ __forceinline__ void group_sums_compacted(const StepConsts<T> &c, con
     L.slot = 0;
 
     // finished paths take the steps of the partial last block (rem of them) and pay; paths still running wait in
-    // the buffer
-    auto settle = [&]() {
+    // the buffer.  one_point: the point every lane's path belongs to, kPool when they are mixed
+    auto settle = [&](uint32_t one_point) {
         double pay = 0.0;
         const bool done = L.count <= c.P2 && L.blk >= n_full;
         const uint32_t finishing = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(done)));
@@ -208,10 +208,15 @@ __device__ __forceinline__ void group_sums_compacted(const StepConsts<T> &c, con
         if (finishing != 0) {
             // the batch's payoffs, point by point, onto the points' running sums: a few dozen instructions in the
             // batches where a path reaches maturity, against eight vector registers for per-lane sums all the time
+            if (one_point != kPool) {   // a batch of fresh paths: they all belong to that point
+                const double total = wave_sum(pay);
+                if (lane == 0) buf.pt_sum[one_point] += total;
+            } else {
 #pragma unroll
-            for (uint32_t s = 0; s < kPool; ++s) {
-                const double total = wave_sum(L.slot == s ? pay : 0.0);
-                if (lane == 0) buf.pt_sum[s] += total;
+                for (uint32_t s = 0; s < kPool; ++s) {
+                    const double total = wave_sum(L.slot == s ? pay : 0.0);
+                    if (lane == 0) buf.pt_sum[s] += total;
+                }
             }
             wave_steps += rem;
             live_steps += finishing * rem;
@@ -262,7 +267,7 @@ __device__ __forceinline__ void group_sums_compacted(const StepConsts<T> &c, con
             L.count = j0 + lane < n_inner ? buf.pt_cnt0[slot] : kNoPath;
             L.blk = 0;
             run_batch<T, LOGSPACE, true>(c, m, key, L, n_full, kCompactBelow, wave_steps, live_steps);
-            settle();
+            settle(slot);
             j0 += kWave;
             if (j0 >= n_inner) {
                 j0 = 0;
@@ -277,7 +282,7 @@ __device__ __forceinline__ void group_sums_compacted(const StepConsts<T> &c, con
             const bool last = none_fresh && parked == take;   // nothing will join them: run to the end
             resume(take);
             run_batch<T, LOGSPACE, false>(c, m, key, L, n_full, last ? 0u : kCompactBelow, wave_steps, live_steps);
-            settle();
+            settle(kPool);
         }
         if (none_fresh) break;
     }

@@ -72,6 +72,7 @@ def parse(argv=None):
     ap.add_argument("--no-store-roofline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--no-nmc", action="store_true", help="skip the BASELINE configs[3] nested-MC side leg")
     ap.add_argument("--accuracy-pairs", type=int, default=1_000_000_000)
     ap.add_argument("--cpu-sample-paths", type=int, default=0)
     ap.add_argument("--rehearse-launch", action="store_true",
@@ -534,7 +535,8 @@ def main(argv=None):
             # imbalance: kernel time against the time the executed steps would take at the in-register kernel's rate
             key = "nmc_wave_f64_window"
             line["roofline"] = valu_roofline(W, stale, key, f"nmc_{args.nmc_strategy}_kernel<double,window>",
-                                             work / (k_ms / 1e3), extra={"work": "64 lanes x steps each wavefront ran"})
+                                             work / (k_ms / 1e3), extra={"work": "64 lanes x steps each wavefront ran; W is the loop over fresh paths, resumed batches run the dearer loop",
+                                                    "valu_slots_resumed_batches": W.get("nmc_wave_f64_window_resumed")})
         if wl != "nmc":
             line.update({"price": fin.price, "std_err": fin.std_err, "ci95": [fin.ci_lo, fin.ci_hi],
                          "bs_closed_form": BS_EXACT, "abs_err_vs_bs": abs(fin.price - BS_EXACT),
@@ -649,6 +651,40 @@ def main(argv=None):
                                  "abs_err_vs_bs": abs(r1.price - BS_EXACT), "within_1e-4": abs(r1.price - BS_EXACT) <= 1e-4,
                                  "within_3se": abs(r1.price - BS_EXACT) <= 3 * r1.std_err,
                                  "seconds": time.perf_counter() - t_acc, "kernel_ms": r1.kernel_ms}
+
+    # BASELINE configs[3] beside the headline: nested MC, 65 536 outer x 252 steps x 1000 inner paths, fp64, with the
+    # reference's bullet window (hello.cu:11-13), two-launch route (outer store + wave-per-point inner stage), one
+    # untimed and two timed passes (~0.2 s each).  `--workload nmc` is the full line for this config.
+    if solo and wl == "european252" and not args.no_nmc:
+        try:
+            n4, s4, i4 = 65_536, 252, 1000
+            opt4 = capi.make_option(**OPTION, **BULLET)
+            t4 = torch.empty(n4 * s4, dtype=torch.float64, device="cuda")
+            c4 = torch.empty(n4 * s4, dtype=torch.int32, device="cuda")
+            o4 = torch.empty(n4 * s4, dtype=torch.float64, device="cuda")
+            runs = []
+            for i in range(3):
+                ro = ctx.simulate_trajectories(opt4, capi.make_sim(n4, s4, capi.F64, 1234 + i, 0, n4), t4, c4)
+                ri = ctx.nmc_inner(opt4, capi.make_sim(n4, s4, capi.F64, 1234 + i + 100_003, 0, n4, i4), t4, c4, o4,
+                                   variant=capi.NMC_WAVE_PER_POINT)
+                runs.append((ro.kernel_ms, ri.kernel_ms, ri.work_steps, ri.live_steps, ri.price))
+            runs = runs[1:]
+            k4 = sum(r[1] for r in runs) / len(runs)
+            w4 = sum(r[2] for r in runs) / len(runs)
+            l4 = sum(r[3] for r in runs) / len(runs)
+            rf = valu_roofline(W, stale, "nmc_wave_f64_window", "nmc_wave_kernel<double,window>", w4 / (k4 / 1e3),
+                               extra={"work": "64 lanes x steps each wavefront ran; W is the loop over fresh paths, resumed batches run the dearer loop",
+                                                    "valu_slots_resumed_batches": W.get("nmc_wave_f64_window_resumed")})
+            line["nmc_config4"] = {
+                "workload": "BASELINE configs[3]: nested MC 65536 x 252 points x 1000 inner paths, fp64, bullet window B=120 P1=10 P2=50",
+                "outer_kernel_ms": sum(r[0] for r in runs) / len(runs), "inner_kernel_ms": k4,
+                "inner_paths_per_s": n4 * s4 * i4 / (k4 / 1e3), "executed_inner_path_steps": w4,
+                "live_inner_path_steps": l4, "lane_efficiency": l4 / w4 if w4 else None,
+                "european_window_inner_path_steps": n4 * i4 * (s4 * (s4 - 1) // 2),
+                "mean_point_price": runs[-1][4], "roofline": rf}
+            del t4, c4, o4
+        except Exception as e:  # the headline must survive a failure of the side measurement
+            line["nmc_config4"] = {"error": str(e)}
 
     if solo and not args.no_cpu_baseline:
         if wl == "nmc":

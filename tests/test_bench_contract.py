@@ -77,7 +77,7 @@ def test_bare_gpus_n_fails_loudly_without_n_devices():
 def test_bench_emits_one_json_line_with_roofline_and_cpu_baseline():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                           "--paths", "1000000", "--cpu-sample-paths", "20000", "--no-store-roofline",
-                          "--no-accuracy", "--no-sweep"], capture_output=True, text=True, timeout=600)
+                          "--no-accuracy", "--no-sweep", "--no-nmc"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

@@ -105,7 +105,7 @@ def asm_of(src: str) -> str:
         return open(out).read()
 
 
-def step_loop(asm: str, symbol: str):
+def step_loop(asm: str, symbol: str, which: str = "shortest"):
     # `symbol` is the mangled name up to and including the template arguments; the parameter list may follow
     m = re.search(r"^%s\w*:.*?\.Lfunc_end" % re.escape(symbol), asm, re.S | re.M)
     if not m:
@@ -134,6 +134,12 @@ def step_loop(asm: str, symbol: str):
                 loops.append(ins)
     if not loops:
         raise SystemExit(f"no Philox loop in {symbol}")
+    n_mul = lambda ins: sum(1 for x in ins if x.split()[0] in ("v_mad_u64_u32", "v_mul_hi_u32"))
+    if which == "fewest_mul":    # the loop whose first Philox round is half scalar (a wave-uniform block index)
+        return min(loops, key=lambda ins: (n_mul(ins), len(ins)))
+    if which == "most_mul":      # the loop with a per-lane block index; innermost = shortest among those
+        top = max(n_mul(ins) for ins in loops if n_mul(ins) <= 24)
+        return min((ins for ins in loops if n_mul(ins) == top), key=len)
     return min(loops, key=len)
 
 
@@ -144,7 +150,10 @@ KERNELS = {
     "price_f32": ("price_f32.hip", "_ZN5mcamd12price_kernelIfLb0ELb0ELi0EEE", 4),
     "store_f32": ("store.hip", "_ZN5mcamd12store_kernelIfLb0ELi0ELb1EEE", 16),
     # nested MC inner stage, fp64, barrier window (BASELINE configs[3]): St is evaluated at every step for the count
-    "nmc_wave_f64_window": ("nmc.hip", "_ZN5mcamd15nmc_wave_kernelIdLb1ELi0ELb0EEE", 2),
+    # two step loops since the lane compaction (csrc/nmc_compact.hpp): batches of fresh paths (block index uniform) and
+    # batches of resumed ones (block index per lane: the first Philox round loses its scalar half)
+    "nmc_wave_f64_window": ("nmc.hip", "_ZN5mcamd15nmc_wave_kernelIdLb1ELi0ELb0EEE", 2, "fewest_mul"),
+    "nmc_wave_f64_window_resumed": ("nmc.hip", "_ZN5mcamd15nmc_wave_kernelIdLb1ELi0ELb0EEE", 2, "most_mul"),
     "price_f64_window": ("price_f64.hip", "_ZN5mcamd12price_kernelIdLb1ELb0ELi0EEE", 2),
 }
 
@@ -153,9 +162,10 @@ def main():
     cache, result, md = {}, {}, ["# VALU issue slots per path-step (gfx950 ISA of the shipped inner loops)\n",
                                  "Generated by tools/count_valu_slots.py; weights from profiles/r01_valu_issue_costs.json.\n"]
     cost = measured_costs()
-    for key, (src, sym, steps) in KERNELS.items():
+    for key, spec_ in KERNELS.items():
+        src, sym, steps = spec_[:3]
         asm = cache.setdefault(src, asm_of(src))
-        lines_ = step_loop(asm, sym)
+        lines_ = step_loop(asm, sym, spec_[3] if len(spec_) > 3 else "shortest")
         # an instruction is keyed by its opcode, plus "(sgpr)" when a full-rate opcode reads a scalar register
         keyed = [(l.split()[0] + (" (sgpr src)" if cycles(l.split()[0]) == 2 and reads_sgpr(l) else ""), line_cycles(l))
                  for l in lines_]

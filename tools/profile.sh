@@ -11,7 +11,7 @@ OUT="$R/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 case "$MODE" in
-  default) BENCH=(python3 "$R/bench.py" --steps 40 --warmup 5 --no-cpu-baseline --no-accuracy --no-sweep) ;;
+  default) BENCH=(python3 "$R/bench.py" --steps 40 --warmup 5 --no-cpu-baseline --no-accuracy --no-sweep --no-nmc) ;;
   nmc)     BENCH=(python3 "$R/bench.py" --workload nmc --steps 1 --warmup 1 --no-cpu-baseline) ;;
   nmc_all) BENCH=(python3 "$R/tools/nmc_strategies.py") ;;
   nmc_eu)  BENCH=(python3 "$R/bench.py" --workload nmc --nmc-window european --steps 1 --warmup 0 --no-cpu-baseline) ;;

@@ -672,7 +672,8 @@ def test_randomised_nested_mc_vs_oracle(ctx, oracle):
     rng = np.random.default_rng(7)
     for case in range(24):
         prec = capi.F64 if case % 4 else capi.F32
-        n_paths, n_steps, n_inner = int(rng.integers(1, 9)), int(rng.integers(2, 24)), int(rng.choice([1, 5, 63, 64, 65, 130, 300, 1000]))
+        # 1..19 outer paths: whole and short task groups (8 adjacent paths share a compaction pool, csrc/nmc_compact.hpp)
+        n_paths, n_steps, n_inner = int(rng.integers(1, 20)), int(rng.integers(2, 24)), int(rng.choice([1, 5, 63, 64, 65, 130, 300, 1000]))
         B = 100.0 * float(rng.choice([0.0, 0.9, 1.0, 1.08, 3.0]))
         P1 = int(rng.integers(0, n_steps))
         P2 = int(rng.integers(P1, n_steps + 1))

@@ -340,6 +340,9 @@ static NmcArgs<T> make_args(const NmcJob &job, const void *d_prices, const int32
 {
     NmcArgs<T> a;
     a.c = make_consts<T>(job.path);
+    // the compacting kernels mark a lane without a path by count = INT32_MAX (kNoPath) and test liveness as
+    // count <= P2: keep P2 below that (no count reaches it: counts start at a stored int32 and grow by one per step)
+    if (a.c.P2 >= kNoPath) a.c.P2 = kNoPath - 1;
     a.seed = job.path.seed;
     a.path_offset = job.path.path_offset;
     a.n_local = job.path.n_local;

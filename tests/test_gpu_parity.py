@@ -614,6 +614,12 @@ def test_nmc_variants_agree_and_european_window(ctx):
     # up to whole wavefronts and whole Philox blocks
     european = n_paths * n_inner * (n_steps * (n_steps - 1) // 2)
     assert ra.live_steps == european == rb.live_steps and european <= ra.work_steps < 1.2 * european
+    # P2 = INT32_MAX (a window that can never close) is the same job: the kernels' "no path in this lane" marker must
+    # not collide with it
+    opt_max = capi.make_option(**BENCH, B=0.0, P1=0, P2=2**31 - 1, use_window=1)
+    a2 = dev(n_paths * n_steps, torch.float64)
+    ctx.nmc_inner(opt_max, inner, traj, cnt, a2, capi.STEP_MAJOR, capi.NMC_WAVE_PER_POINT)
+    assert torch.equal(a2, a)
     # inner price of point (s, q) estimates e^{-rT} E[(S_T-K)+ | S_s]: compare with closed form * growth, loosely
     S = traj.view(n_steps, n_paths)[5].cpu().numpy()
     tau = 1.0 - 6 / 12

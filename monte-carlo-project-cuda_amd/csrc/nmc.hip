@@ -10,20 +10,20 @@
 // state of whichever thread happens to run it (the reference re-uses one curandState per thread
 // across tasks, so its numbers depend on the launch shape).
 //
-// WAVE_PER_POINT is the gfx950-shaped one: a point is a task for ONE wavefront; its 64 lanes
-// stride over the inner paths and the point's sum is a pure wave64 shuffle reduction — no LDS,
-// no barrier, against the reference's 1024-thread block + 5-barrier tree per task.
-// Tasks are ordered step-major, so the long tasks (small step, many remaining steps) come
-// first and the short ones fill the tail.  A point whose count already exceeds P2 can never pay
-// (inc/nmc.cuh:53,330) and is skipped by the whole wave.  Tasks are handed out dynamically: the
-// grid is persistent (a few workgroups per CU) and every wavefront pulls the next chunk of kNmcChunk
-// consecutive tasks from one device-scope counter.  With the bullet window task lengths differ widely
-// (a wavefront runs until its LAST lane's window closes), and under a static assignment a finished
-// wavefront idles until the slowest wavefront of its workgroup retires (measured: VALU 85 % busy,
-// profiles/r02c_nmc_pmc_per_kernel.json); pulled tasks keep every wavefront busy until the queue is empty.
-// One returning atomic per chunk: 4M dequeues over ~0.5 s, far below the ~88 per microsecond one
-// counter sustains (MI355X_MICROARCH.md, dequeue).  Every wavefront leaves its loop on the first
-// index past the end, so the grid always drains.
+// WAVE_PER_POINT is the gfx950-shaped one: points are priced by ONE wavefront each way — no workgroup barrier,
+// against the reference's 1024-thread block + 5-barrier tree per task.  A task is a GROUP of kPool points (one
+// step of kPool adjacent outer paths); tasks are ordered step-major, so the long ones (small step, many remaining
+// steps) come first and the short ones fill the tail.  A point whose count already exceeds P2 can never pay
+// (inc/nmc.cuh:53,330) and none of its paths is started.  Tasks are handed out dynamically: the grid is
+// persistent (a few workgroups per CU) and every wavefront pulls the next group from one device-scope counter.
+// With the bullet window task lengths differ widely, and under a static assignment a finished wavefront idles
+// until the slowest wavefront of its workgroup retires (measured: VALU 85 % busy); pulled tasks keep every
+// wavefront busy until the queue is empty.  One returning atomic per group: 2M dequeues over ~0.2 s, far below
+// the ~88 per microsecond one counter sustains (MI355X_MICROARCH.md, dequeue).  Every wavefront leaves its loop
+// on the first index past the end, so the grid always drains.
+// With a window, the group's continuation paths are ONE pool for the wavefront's lane compaction
+// (nmc_compact.hpp): lanes whose path is over are refilled instead of waited for.  Without a window every path
+// runs every step and the group's points are priced one after the other, lanes striding over the inner paths.
 // Each inner path restarts from the stored (St, count); the reference's carry-over between
 // successive inner paths of one thread is a defect and is not reproduced, and the
 // output is written, not atomically added to unzeroed memory.

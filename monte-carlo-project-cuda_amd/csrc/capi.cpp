@@ -419,10 +419,10 @@ int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *
     HIP_TRY(hipSetDevice(ctx->device));
     const mcamd::PathJob job = make_job(opt, sim);
     const int rec = (job.vr & 2) ? 5 : 2;
-    const uint32_t grid = mcamd::price_grid(job.n_local, job.n_sim);
+    const uint32_t grid = mcamd::price_grid(job, ctx->compute_units);
     if (int rc = ensure_partials(ctx, grid, rec)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    HIP_TRY(mcamd::launch_price(job, ctx->d_partials, grid, ctx->stream));
+    HIP_TRY(mcamd::launch_price(job, ctx->compute_units, ctx->d_partials, ctx->d_queue, grid, ctx->stream));
     return finish_pricing(ctx, grid, rec, opt, sim, res);
 }
 
@@ -442,12 +442,12 @@ int mcamd_price_paths_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mca
     }
     const mcamd::PathJob job = make_job(opt, sim);
     const int rec = (job.vr & 2) ? 5 : 2;
-    const uint32_t grid = mcamd::price_grid(job.n_local, job.n_sim);
+    const uint32_t grid = mcamd::price_grid(job, ctx->compute_units);
     // growing the scratch buffer frees the old one: wait for work that may still read it
     if (static_cast<uint64_t>(grid) * rec > ctx->partial_capacity) HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (int rc = ensure_partials(ctx, grid, rec)) return rc;
     HIP_TRY(hipEventRecord(ctx->ring0[slot], ctx->stream));
-    HIP_TRY(mcamd::launch_price(job, ctx->d_partials, grid, ctx->stream));
+    HIP_TRY(mcamd::launch_price(job, ctx->compute_units, ctx->d_partials, ctx->d_queue, grid, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ring1[slot], ctx->stream));
     HIP_TRY(mcamd::launch_final_reduce(ctx->d_partials, grid, rec, d_stats, ctx->stream,
                                        static_cast<double>(sim->n_paths_local)));

@@ -27,8 +27,11 @@ struct PathJob {
 constexpr uint32_t kMaxGrid = 1u << 20;  // blocks; beyond this the kernels grid-stride
 
 // number of partial records (one per block) a launch with this many local paths writes
-uint32_t price_grid(uint64_t n_local, uint32_t n_sim);
-hipError_t launch_price(const PathJob &job, double *d_partials, uint32_t grid, hipStream_t stream);
+// compute_units: of the device the job runs on (0: 256).  d_queue: one 64-bit word of device memory, used (and zeroed on
+// `stream`) when the job goes to the lane-compacting window kernel, which pulls its tasks from it.
+uint32_t price_grid(const PathJob &job, uint32_t compute_units);
+hipError_t launch_price(const PathJob &job, uint32_t compute_units, double *d_partials, unsigned long long *d_queue,
+                        uint32_t grid, hipStream_t stream);
 
 uint32_t store_grid(uint64_t n_local, int precision);
 hipError_t launch_store(const PathJob &job, int layout, void *d_traj, int32_t *d_counts, void *d_payoffs,

@@ -89,11 +89,13 @@ __device__ __forceinline__ void price_group(const NmcArgs<T> &a, const StepConst
             parked.pt_log_start[lane] =
                 (cnt0 != kNoPath && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
             parked.pt_subsequence[lane] = ((a.path_offset + path0 + lane) * a.n_steps + step) * a.n_inner;
+            parked.pt_n[lane] = a.n_inner;
             parked.pt_sum[lane] = 0.0;
+            parked.pt_sumsq[lane] = 0.0;
         }
         wave_lds_fence();
         uint32_t steps_run = 0, live_steps = 0;
-        group_sums_compacted<T, LOGSPACE>(c, m, key, a.n_inner, remaining, parked, steps_run, live_steps);
+        group_sums_compacted<T, LOGSPACE>(c, m, key, remaining, parked, steps_run, live_steps);
         wave_lds_fence();
 #pragma unroll
         for (uint32_t s = 0; s < kPool; ++s) {

@@ -41,7 +41,9 @@ struct SurvivorBuf {
     T pt_St0[kPool];                  // stored outer price
     T pt_log_start[kPool];            // ln(St0 / S_start) in exponent units (0 where unused)
     int32_t pt_cnt0[kPool];           // stored outer count; kNoPath marks a point that is absent or already closed
+    uint32_t pt_n[kPool];             // continuation paths of the point
     double pt_sum[kPool];             // running sum of the point's payoffs (lane 0 adds each batch's total)
+    double pt_sumsq[kPool];           // and of their squares
 };
 
 // What a kernel declares in LDS per wavefront: the buffer when there is a window, nothing otherwise.
@@ -170,13 +172,14 @@ __device__ __forceinline__ void run_batch(const StepConsts<T> &c, const MathCtx<
 }
 
 // Sums of the window payoffs of the continuation paths of a group's points, into buf.pt_sum[s] for point s (the
-// caller zeroes them).  The points are described in buf.pt_* (pt_cnt0 = kNoPath: skip); all have
+// caller zeroes them), their squares into buf.pt_sumsq[s].  The points are described in buf.pt_* (pt_cnt0 = kNoPath:
+// skip; pt_n paths each); all have
 // `remaining` steps to go and n_inner paths; path j of point s uses Philox subsequence pt_subsequence[s] + j, as the
 // uncompacted loop does.
 template <typename T, bool LOGSPACE>
 __device__ __forceinline__ void group_sums_compacted(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
-                                                     uint32_t n_inner, uint32_t remaining, SurvivorBuf<T> &buf,
-                                                     uint32_t &wave_steps, uint32_t &live_steps)
+                                                     uint32_t remaining, SurvivorBuf<T> &buf, uint32_t &wave_steps,
+                                                     uint32_t &live_steps)
 {
     constexpr int NB = Normals<T>::kPerBlock;
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -209,13 +212,20 @@ __device__ __forceinline__ void group_sums_compacted(const StepConsts<T> &c, con
             // the batch's payoffs, point by point, onto the points' running sums: a few dozen instructions in the
             // batches where a path reaches maturity, against eight vector registers for per-lane sums all the time
             if (one_point != kPool) {   // a batch of fresh paths: they all belong to that point
-                const double total = wave_sum(pay);
-                if (lane == 0) buf.pt_sum[one_point] += total;
+                const double total = wave_sum(pay), total_sq = wave_sum(pay * pay);
+                if (lane == 0) {
+                    buf.pt_sum[one_point] += total;
+                    buf.pt_sumsq[one_point] += total_sq;
+                }
             } else {
 #pragma unroll
                 for (uint32_t s = 0; s < kPool; ++s) {
-                    const double total = wave_sum(L.slot == s ? pay : 0.0);
-                    if (lane == 0) buf.pt_sum[s] += total;
+                    const double mine = L.slot == s ? pay : 0.0;
+                    const double total = wave_sum(mine), total_sq = wave_sum(mine * mine);
+                    if (lane == 0) {
+                        buf.pt_sum[s] += total;
+                        buf.pt_sumsq[s] += total_sq;
+                    }
                 }
             }
             wave_steps += rem;
@@ -259,17 +269,18 @@ __device__ __forceinline__ void group_sums_compacted(const StepConsts<T> &c, con
         while (slot < kPool && __builtin_amdgcn_readfirstlane(buf.pt_cnt0[slot]) == kNoPath) ++slot;   // absent or closed
         if (slot < kPool) {   // the next 64 fresh paths
             const T St0 = buf.pt_St0[slot], log_start = buf.pt_log_start[slot];
+            const uint32_t n_here = __builtin_amdgcn_readfirstlane(buf.pt_n[slot]);
             L.ps = PathState<T>::start(St0);
             if (!LOGSPACE) L.ps.arm_barrier(c.logB - log_start);   // ln(B / St0) = ln(B / S_start) - ln(St0 / S_start)
             L.acc = log_start;
             L.slot = slot;
             L.subsequence = buf.pt_subsequence[slot] + (j0 + lane);
-            L.count = j0 + lane < n_inner ? buf.pt_cnt0[slot] : kNoPath;
+            L.count = j0 + lane < n_here ? buf.pt_cnt0[slot] : kNoPath;
             L.blk = 0;
             run_batch<T, LOGSPACE, true>(c, m, key, L, n_full, kCompactBelow, wave_steps, live_steps);
             settle(slot);
             j0 += kWave;
-            if (j0 >= n_inner) {
+            if (j0 >= n_here) {
                 j0 = 0;
                 ++slot;
             }

@@ -8,4 +8,10 @@ hipError_t launch_price_f32(const PathJob &j, double *d_partials, uint32_t grid,
     return launch_price_t<float>(j, d_partials, grid, stream);
 }
 
+hipError_t launch_price_compact_f32(const PathJob &j, double *d_partials, unsigned long long *d_queue, uint32_t grid,
+                                    hipStream_t stream)
+{
+    return launch_price_compact_t<float>(j, d_partials, d_queue, grid, stream);
+}
+
 }  // namespace mcamd

@@ -22,6 +22,7 @@
 #pragma once
 
 #include "path_consts.hpp"
+#include "nmc_compact.hpp"
 
 namespace mcamd {
 
@@ -64,6 +65,87 @@ __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *_
 #pragma unroll
         for (int i = 0; i < N; ++i) partials[static_cast<uint64_t>(N) * blockIdx.x + i] = acc[i];
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Window payoff, plain estimator, MANY paths: the lane-compacting form (nmc_compact.hpp).  With a window that can
+// close (bullet option: payoff only while P1 <= count <= P2) most paths are over long before maturity, but a
+// wavefront of the kernel above runs until its LAST path is — with 64 unrelated paths per wavefront that is nearly
+// always maturity.  Here a wavefront takes GROUPS of kPool x kSlice consecutive paths from a device-scope queue and
+// runs each group as one compaction pool: lanes whose path is over are refilled with fresh paths, the few long-lived
+// paths are parked in LDS and resumed 64 at a time.  Every path draws the same numbers and takes the same steps as
+// in price_kernel (same Philox subsequence = global path id, same arithmetic), so its payoff is bit-identical; the
+// sums differ by summation order only.  Chosen by the launcher when the job has enough groups to fill the chip.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSlice = 128;                      // paths per pool slot: a group is kPool * kSlice = 1024 paths
+constexpr uint64_t kGroupPaths = static_cast<uint64_t>(kPool) * kSlice;
+
+template <typename T, bool LOGSPACE>
+__global__ __launch_bounds__(kBlock) void price_window_compact_kernel(PriceArgs<T> a, double *__restrict__ partials,
+                                                                      unsigned long long *__restrict__ queue)
+{
+    const MathCtx<T> m = MathCtx<T>::init();
+    const PhiloxKeys key = PhiloxKeys::make(a.seed);
+    StepConsts<T> c = resident(a.c);
+    if (c.P2 >= kNoPath) c.P2 = kNoPath - 1;   // "count <= P2" must stay false for a lane without a path
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    __shared__ SurvivorBuf<T> s_parked[kBlock / kWave];
+    SurvivorBuf<T> &buf = s_parked[threadIdx.x / kWave];
+    const uint64_t n_groups = (a.n_local + kGroupPaths - 1) / kGroupPaths;
+    double acc[2] = {0.0, 0.0};
+    for (;;) {
+        unsigned long long first = 0;
+        if (lane == 0) first = atomicAdd(queue, 1ull);
+        const uint64_t g = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(first >> 32))) << 32) |
+                           __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(first));
+        if (g >= n_groups) break;
+        if (lane < kPool) {   // lane s describes slice s of the group: kSlice consecutive paths (the last may be short)
+            const uint64_t base = g * kGroupPaths + static_cast<uint64_t>(lane) * kSlice;
+            const uint64_t left = base < a.n_local ? a.n_local - base : 0;
+            buf.pt_n[lane] = static_cast<uint32_t>(left < kSlice ? left : kSlice);
+            buf.pt_cnt0[lane] = (left == 0 || c.Ik > c.P2) ? kNoPath : c.Ik;
+            buf.pt_St0[lane] = c.S_start;
+            buf.pt_log_start[lane] = T(0);
+            buf.pt_subsequence[lane] = a.path_offset + base;
+            buf.pt_sum[lane] = 0.0;
+            buf.pt_sumsq[lane] = 0.0;
+        }
+        wave_lds_fence();
+        uint32_t steps_run = 0, live_steps = 0;
+        group_sums_compacted<T, LOGSPACE>(c, m, key, c.n_sim, buf, steps_run, live_steps);
+        wave_lds_fence();
+        if (lane < kPool) {
+            acc[0] += buf.pt_sum[lane];
+            acc[1] += buf.pt_sumsq[lane];
+        }
+        wave_lds_fence();   // the next group's description must not overtake these reads
+    }
+    block_sumN<kBlock, 2>(acc);
+    if (threadIdx.x == 0) {
+        partials[2 * static_cast<uint64_t>(blockIdx.x)] = acc[0];
+        partials[2 * static_cast<uint64_t>(blockIdx.x) + 1] = acc[1];
+    }
+}
+
+// Compaction pays once every SIMD can be kept busy with whole groups; below that the one-path-per-thread kernel's
+// wider parallelism wins.
+inline bool price_compacts(const PathJob &j, uint32_t compute_units)
+{
+    const uint64_t cus = compute_units ? compute_units : 256;
+    return j.window && j.vr == 0 && j.n_sim >= 8 && j.n_local >= cus * 16 * kGroupPaths;
+}
+
+template <typename T>
+static hipError_t launch_price_compact_t(const PathJob &j, double *d_partials, unsigned long long *d_queue, uint32_t grid,
+                                         hipStream_t stream)
+{
+    const PriceArgs<T> a{make_consts<T>(j), j.seed, j.path_offset, j.n_local, j.control_mean};
+    const hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    const dim3 g(grid), b(kBlock);
+    if (j.logspace) hipLaunchKernelGGL((price_window_compact_kernel<T, true>), g, b, 0, stream, a, d_partials, d_queue);
+    else hipLaunchKernelGGL((price_window_compact_kernel<T, false>), g, b, 0, stream, a, d_partials, d_queue);
+    return hipGetLastError();
 }
 
 template <typename T, bool WINDOW, bool LOGSPACE>

@@ -804,6 +804,40 @@ def test_barrier_test_band_scales_with_path_length(ctx, oracle, n_paths, n_steps
     assert math.isclose(st.sum, res.sum, rel_tol=1e-13)
 
 
+@pytest.mark.parametrize("prec", [capi.F32, capi.F64])
+@pytest.mark.parametrize("flags", [0, capi.FLAG_LOG_SPACE])
+def test_bullet_pricing_of_many_paths_compacts_and_changes_nothing(ctx, oracle, prec, flags):
+    # mcamd_price_paths with a window over >= 4.2M paths runs the lane-compacting kernel (csrc/price_impl.hpp:
+    # price_window_compact_kernel); below that, one path per thread.  The same job priced whole (compacting) and as
+    # three shards below the threshold (not compacting) must give the same sums up to summation order, and both must
+    # match the oracle's per-path loop on a slice of the id space.  6 000 037 paths: a ragged last group.
+    n, n_steps = 6_000_037, 40
+    opt = capi.make_option(**BENCH, B=104.0, P1=3, P2=9, use_window=1)
+    whole = ctx.price_paths(opt, capi.make_sim(n, n_steps, prec, seed=77, flags=flags))
+    cuts = [0, 2_000_000, 4_000_001, n]
+    parts = [ctx.price_paths(opt, capi.make_sim(n, n_steps, prec, seed=77, path_offset=a, n_paths_local=b - a, flags=flags))
+             for a, b in zip(cuts[:-1], cuts[1:])]
+    s1, s2 = sum(p.sum for p in parts), sum(p.sumsq for p in parts)
+    rel = 1e-11 if prec == capi.F64 else 1e-9          # identical per-path payoffs: only the fp64 summation order differs
+    assert math.isclose(whole.sum, s1, rel_tol=rel) and math.isclose(whole.sumsq, s2, rel_tol=rel) and whole.sum > 0
+    assert whole.n == n
+    # the compacting kernel is a persistent grid (4 workgroups per CU), the plain one a block per 256 paths
+    assert whole.grid <= 2048 and parts[0].grid == -(-2_000_000 // 256)
+    # the oracle follows 300k paths of the job: ids [3.0M, 3.3M), priced on the GPU as the difference of two prefixes
+    lo, cnt = 3_000_000, 300_000
+    ref = oracle.mc_paths(oparams(oracle, opt, capi.make_sim(n, n_steps, prec, seed=77, flags=flags)), prec, lo, cnt,
+                          threads=oracle.max_threads())
+    big = ctx.price_paths(opt, capi.make_sim(n, n_steps, prec, seed=77, path_offset=0, n_paths_local=lo, flags=flags))
+    big2 = ctx.price_paths(opt, capi.make_sim(n, n_steps, prec, seed=77, path_offset=0, n_paths_local=lo + cnt, flags=flags))
+    tol = 1e-9 if prec == capi.F64 else 2e-4
+    assert math.isclose(big2.sum - big.sum, ref["sum"], rel_tol=tol), (big2.sum - big.sum, ref["sum"])
+    # a shard that does reach the threshold, deep in the id space, equals the same ids priced in small pieces
+    deep = ctx.price_paths(opt, capi.make_sim(1 << 40, n_steps, prec, seed=77, path_offset=(1 << 39) + 5, n_paths_local=4_400_000, flags=flags))
+    pieces = [ctx.price_paths(opt, capi.make_sim(1 << 40, n_steps, prec, seed=77, path_offset=(1 << 39) + 5 + k * 1_100_000,
+                                                  n_paths_local=1_100_000, flags=flags)) for k in range(4)]
+    assert math.isclose(deep.sum, sum(p.sum for p in pieces), rel_tol=rel)
+
+
 def test_full_size_config4_reference_bullet_window(ctx, oracle):
     # config 4 as hello.cu runs it: nested MC, 65 536 outer x 252 steps x 1000 inner, fp64, bullet window B = 120,
     # P1 = 10, P2 = 50 (hello.cu:11-15).  Checks: (1) a sample of points against oracle_nmc_point (1e-11);

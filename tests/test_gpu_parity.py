@@ -807,7 +807,7 @@ def test_barrier_test_band_scales_with_path_length(ctx, oracle, n_paths, n_steps
 @pytest.mark.parametrize("prec", [capi.F32, capi.F64])
 @pytest.mark.parametrize("flags", [0, capi.FLAG_LOG_SPACE])
 def test_bullet_pricing_of_many_paths_compacts_and_changes_nothing(ctx, oracle, prec, flags):
-    # mcamd_price_paths with a window over >= 4.2M paths runs the lane-compacting kernel (csrc/price_impl.hpp:
+    # mcamd_price_paths with a window over >= 3.1M paths runs the lane-compacting kernel (csrc/price_impl.hpp:
     # price_window_compact_kernel); below that, one path per thread.  The same job priced whole (compacting) and as
     # three shards below the threshold (not compacting) must give the same sums up to summation order, and both must
     # match the oracle's per-path loop on a slice of the id space.  6 000 037 paths: a ragged last group.

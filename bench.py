@@ -652,6 +652,21 @@ def main(argv=None):
                                  "within_3se": abs(r1.price - BS_EXACT) <= 3 * r1.std_err,
                                  "seconds": time.perf_counter() - t_acc, "kernel_ms": r1.kernel_ms}
 
+    # the reference's bullet option (hello.cu:11-13: B = 120, P1 = 10, P2 = 50) on configs[1]'s shape, 10M paths x 252
+    # steps, fp64: the window closes for most paths after ~51 steps, and from 3.1M paths on the library prices such
+    # jobs with its lane-compacting kernel (csrc/price_impl.hpp)
+    if solo and wl == "european252" and not args.no_nmc:
+        try:
+            optb = capi.make_option(**OPTION, **BULLET)
+            rb_ = [ctx.price_paths(optb, capi.make_sim(n_total, n_steps, prec, 1234 + i, lo, per_gpu)) for i in range(6)]
+            kb = sum(r.kernel_ms for r in rb_[2:]) / len(rb_[2:])
+            line["bullet_252"] = {"workload": f"bullet call B=120 P1=10 P2=50, {per_gpu} paths x {n_steps} steps, fp64, in-register",
+                                  "kernel_ms": kb, "paths_per_s_kernel": per_gpu / (kb / 1e3), "price": rb_[-1].price,
+                                  "std_err": rb_[-1].std_err, "grid": rb_[-1].grid,
+                                  "kernel": "price_window_compact_kernel<double>" if rb_[-1].grid <= 4096 else "price_kernel<double,window>"}
+        except Exception as e:
+            line["bullet_252"] = {"error": str(e)}
+
     # BASELINE configs[3] beside the headline: nested MC, 65 536 outer x 252 steps x 1000 inner paths, fp64, with the
     # reference's bullet window (hello.cu:11-13), two-launch route (outer store + wave-per-point inner stage), one
     # untimed and two timed passes (~0.2 s each).  `--workload nmc` is the full line for this config.

@@ -1,19 +1,22 @@
-// nmc_compact.hpp — the continuation paths of ONE nested-MC point, run by one wavefront with lane compaction.
+// nmc_compact.hpp — lane compaction for paths with a barrier window: one wavefront runs a POOL of paths and keeps its
+// lanes busy with paths that are still alive.  Used by the nested-MC kernels (nmc.hip: the pool is the continuation
+// paths of a group of kPool stored points) and by bullet pricing of many paths (price_impl.hpp: the pool is kPool slices
+// of consecutive paths).
 //
-// With a barrier window (inc/nmc.cuh:47-66: payoff only while P1 <= count <= P2) a continuation path is over as
-// soon as its count passes P2, and most are after a few dozen steps — but the few that climbed above the barrier
-// live to maturity, and a wavefront that waits for its last lane runs ~250 steps with two or three lanes working
-// (measured on BASELINE configs[3] with the reference's window B = 120, P1 = 10, P2 = 50: 36 % of the executed
-// lane-steps belong to paths that are still alive).  So the wavefront does not wait: once kCompactBelow or fewer
-// of its lanes are still running, those lanes park their path (product, exponent, count, path index, next Philox
-// block: 32 bytes in fp64) in the wavefront's LDS buffer and the wavefront starts the next 64 fresh paths; whenever
-// 64 parked paths have gathered they are resumed together, full width, under the same rule.  Philox is
-// counter-based, so a resumed path continues its own stream at its own block whatever lane it lands in:
-// every path's payoff is bit-identical to the uncompacted loop, only the summation order of the point's mean
-// changes (deterministically: the schedule depends on the points alone, not on timing).
-// The pool a wavefront draws fresh paths from is a GROUP of kPool points — the same step of kPool adjacent outer
-// paths, so all their continuation paths have the same number of steps to go — which leaves fewer half-empty
-// batches at the end than one point alone would (the last batch of a pool runs to completion whatever its width).
+// With a barrier window (inc/nmc.cuh:47-66, inc/trajectories.cuh:149: payoff only while P1 <= count <= P2) a path is
+// over as soon as its count passes P2, and most are after a few dozen steps — but the few that climbed above the
+// barrier live to maturity, and a wavefront that waits for its last lane runs ~250 steps with two or three lanes
+// working (measured on BASELINE configs[3] with the reference's window B = 120, P1 = 10, P2 = 50: 37 % of the
+// executed lane-steps belong to paths that are still alive).  So the wavefront does not wait: once kCompactBelow or
+// fewer of its lanes are still running, those lanes park their path (product, barrier accumulator, exponent, count,
+// path index, point, next Philox block: 36 bytes in fp64) in the wavefront's LDS buffer and the wavefront starts the
+// next 64 fresh paths; whenever 64 parked paths have gathered they are resumed together, full width, under the same
+// rule; the last batch of a pool runs to completion whatever its width.  Philox is counter-based, so a resumed path
+// continues its own stream at its own block whatever lane it lands in: every path's payoff is bit-identical to the
+// uncompacted loop, only the summation order of a point's sum changes (deterministically: the schedule depends on
+// the pool alone, not on timing).
+// A pool spans kPool points with the same number of steps to go (nested MC: one step of kPool adjacent outer paths),
+// which leaves far fewer half-empty batches at the end than one point alone would (lane efficiency 0.84 -> 0.94).
 #pragma once
 
 #include "mc_device.hpp"
@@ -38,10 +41,10 @@ struct SurvivorBuf {
     uint32_t slot[kSurvivorCap];   // which point of the group it belongs to
     // the group's points (written by the wavefront when it takes the group)
     uint64_t pt_subsequence[kPool];   // Philox subsequence of the point's continuation path 0
-    T pt_St0[kPool];                  // stored outer price
+    T pt_St0[kPool];                  // start price (nested MC: the stored outer price)
     T pt_log_start[kPool];            // ln(St0 / S_start) in exponent units (0 where unused)
-    int32_t pt_cnt0[kPool];           // stored outer count; kNoPath marks a point that is absent or already closed
-    uint32_t pt_n[kPool];             // continuation paths of the point
+    int32_t pt_cnt0[kPool];           // start count (the stored outer count); kNoPath: point absent or already closed
+    uint32_t pt_n[kPool];             // paths of the point
     double pt_sum[kPool];             // running sum of the point's payoffs (lane 0 adds each batch's total)
     double pt_sumsq[kPool];           // and of their squares
 };

@@ -25,8 +25,17 @@ slots:            ## recount VALU issue slots of the shipped inner loops -> prof
 tables:           ## regenerate the fp64 math tables (needs mpmath)
 	$(PY) tools/gen_tables64.py
 
+HIPCC ?= hipcc
+PROBE_FLAGS = --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Imonte-carlo-project-cuda_amd/csrc
+PROBES = clock_probe init_probe store_variants ubench_bank ubench_valu ubench_hbm_write naive_port_baseline
+
+probes: $(addprefix tools/,$(PROBES))   ## the diagnostic binaries behind profiles/ (run them on an MI355X)
+
+tools/%: tools/%.hip
+	$(HIPCC) $(PROBE_FLAGS) $< -o $@
+
 clean:
 	rm -rf monte-carlo-project-cuda_amd/csrc/build monte-carlo-project-cuda_amd/libmcamd.so oracle/liboracle.so oracle/_ref
 	$(MAKE) -C examples clean
 
-.PHONY: build examples test-cpu test-gpu smoke bench slots tables clean
+.PHONY: build examples test-cpu test-gpu smoke bench slots tables probes clean

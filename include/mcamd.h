@@ -53,9 +53,10 @@ extern "C" {
 #define MCAMD_PATH_MAJOR 1 /* a[path * n_steps + step]        — the reference's layout
                               (inc/trajectories.cuh:304-305, inc/testing.cuh:69) */
 
-/* nested-MC strategies; all give the same per-point prices (the third reference strategy, the fused
- * single launch, is mcamd_nmc_fused) */
-#define MCAMD_NMC_WAVE_PER_POINT 0  /* replaces compute_nmc_optimal, inc/nmc.cuh:280-386 */
+/* nested-MC strategies; all give the same per-point prices up to fp64 summation order (the third reference strategy,
+ * the fused single launch, is mcamd_nmc_fused and equals WAVE_PER_POINT bit for bit) */
+#define MCAMD_NMC_WAVE_PER_POINT 0  /* replaces compute_nmc_optimal, inc/nmc.cuh:280-386.  The fast one: with a window,
+                                       wavefronts refill lanes whose path is over instead of waiting for the last */
 #define MCAMD_NMC_BLOCK_PER_POINT 1 /* replaces compute_nmc_one_block_per_point, inc/nmc.cuh:12-108 */
 
 /* mcamd_sim.flags */
@@ -183,7 +184,10 @@ int mcamd_memcpy_to_device(mcamd_ctx *ctx, void *d_dst, const void *h_src, uint6
  *     simulateOptionPriceMultipleBlockGPUwithReduce  inc/trajectories.cuh:54-113
  *   wrapper_gpu_bullet_option[_atomic]  inc/wrappers.cuh:59-125  (use_window = 1)
  *     simulateBulletOptionPriceMultipleBlockGPU[atomic]  inc/trajectories.cuh:115-271
- * and is the multi-step European pricer of BASELINE configs 2 and 5 (use_window = 0). */
+ * and is the multi-step European pricer of BASELINE configs 2 and 5 (use_window = 0).
+ * The library picks the kernel: window jobs of millions of paths (plain estimator) run the lane-compacting kernel, the
+ * rest one path per thread; a path's payoff does not depend on which (same Philox stream, same arithmetic), so any
+ * sharding of a job gives the same sums up to fp64 summation order. */
 int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, mcamd_result *res);
 
 /* Asynchronous form of mcamd_price_paths: enqueues the simulation kernel and the final reduction on the context's

@@ -94,7 +94,7 @@ __device__ __forceinline__ void price_group(const NmcArgs<T> &a, const StepConst
             parked.pt_sumsq[lane] = 0.0;
         }
         wave_lds_fence();
-        uint32_t steps_run = 0, live_steps = 0;
+        uint64_t steps_run = 0, live_steps = 0;   // wave-uniform; a pool may hold billions of lane-steps
         group_sums_compacted<T, LOGSPACE>(c, m, key, remaining, parked, steps_run, live_steps);
         wave_lds_fence();
 #pragma unroll

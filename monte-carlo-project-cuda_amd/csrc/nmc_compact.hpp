@@ -148,8 +148,8 @@ struct BlockDraws {
 // stays scalar and the first Philox round keeps its scalar half.
 template <typename T, bool LOGSPACE, bool UNIFORM>
 __device__ __forceinline__ void run_batch(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
-                                          InnerLane<T> &L, uint32_t n_full, uint32_t live_limit, uint32_t &wave_steps,
-                                          uint32_t &live_steps)
+                                          InnerLane<T> &L, uint32_t n_full, uint32_t live_limit, uint64_t &wave_steps,
+                                          uint64_t &live_steps)
 {
     constexpr int NB = Normals<T>::kPerBlock;
     const uint64_t subsequence = L.subsequence;
@@ -161,7 +161,7 @@ __device__ __forceinline__ void run_batch(const StepConsts<T> &c, const MathCtx<
         const uint32_t live = __builtin_amdgcn_readfirstlane(
             static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(run))));
         if (live <= live_limit) break;
-        live_steps += live * NB;
+        live_steps += static_cast<uint64_t>(live) * NB;
         if (run) {
             BlockDraws<T, LOGSPACE> d;
             d.fill(c, m, key, subsequence, UNIFORM ? kb : L.blk);
@@ -171,7 +171,7 @@ __device__ __forceinline__ void run_batch(const StepConsts<T> &c, const MathCtx<
         }
     }
     if (UNIFORM) L.blk = kb;
-    wave_steps += static_cast<uint32_t>(NB) * static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(kb));
+    wave_steps += static_cast<uint64_t>(NB) * static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(kb));
 }
 
 // Sums of the window payoffs of the continuation paths of a group's points, into buf.pt_sum[s] for point s (the
@@ -181,8 +181,8 @@ __device__ __forceinline__ void run_batch(const StepConsts<T> &c, const MathCtx<
 // uncompacted loop does.
 template <typename T, bool LOGSPACE>
 __device__ __forceinline__ void group_sums_compacted(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &key,
-                                                     uint32_t remaining, SurvivorBuf<T> &buf, uint32_t &wave_steps,
-                                                     uint32_t &live_steps)
+                                                     uint32_t remaining, SurvivorBuf<T> &buf, uint64_t &wave_steps,
+                                                     uint64_t &live_steps)
 {
     constexpr int NB = Normals<T>::kPerBlock;
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -232,7 +232,7 @@ __device__ __forceinline__ void group_sums_compacted(const StepConsts<T> &c, con
                 }
             }
             wave_steps += rem;
-            live_steps += finishing * rem;
+            live_steps += static_cast<uint64_t>(finishing) * rem;
         }
         const bool waits = L.count <= c.P2 && L.blk < n_full;
         const uint64_t mask = __builtin_amdgcn_ballot_w64(waits);

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void price_window_compact_kernel(PriceArgs<
             buf.pt_sumsq[lane] = 0.0;
         }
         wave_lds_fence();
-        uint32_t steps_run = 0, live_steps = 0;
+        uint64_t steps_run = 0, live_steps = 0;
         group_sums_compacted<T, LOGSPACE>(c, m, key, c.n_sim, buf, steps_run, live_steps);
         wave_lds_fence();
         if (lane < kPool) {

@@ -49,11 +49,13 @@ __device__ __forceinline__ float vgpr_resident(float s)
 // The ten round-key pairs of Philox4x32-10 for one seed, in vector registers (20 VGPRs, built once per kernel).
 struct PhiloxKeys {
     uint32_t k0[10], k1[10];
+    uint32_t k1_first;   // k1[0] once more, left to the compiler (a scalar register): round 1 folds it into scalar terms
     __device__ __forceinline__ static PhiloxKeys make(uint64_t seed)
     {
         constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
         PhiloxKeys k;
         uint32_t a = static_cast<uint32_t>(seed), b = static_cast<uint32_t>(seed >> 32);
+        k.k1_first = b;
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             k.k0[i] = vgpr_resident(a);
@@ -74,7 +76,8 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
         const uint64_t p0 = static_cast<uint64_t>(M0) * c0;
         const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
         const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ key.k0[0];
-        const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ (c3 ^ key.k1[0]);
+        // hi(M0 c0) and the key are both wave-uniform there: their xor runs on the scalar unit, leaving one vector xor
+        const uint32_t n2 = (static_cast<uint32_t>(p0 >> 32) ^ key.k1_first) ^ c3;
         c1 = static_cast<uint32_t>(p1);
         c3 = static_cast<uint32_t>(p0);
         c0 = n0;

@@ -23,8 +23,14 @@
 
 namespace mcamd {
 
-constexpr uint32_t kPool = 8;                                 // points per group (a group is one task of the kernels)
-constexpr uint32_t kCompactBelow = 48;                       // hand over when this many lanes or fewer still run
+#ifndef MCAMD_POOL            // overridable for the same-box comparisons of profiles/r02_nmc_variants.txt only
+#define MCAMD_POOL 8
+#endif
+#ifndef MCAMD_COMPACT_BELOW
+#define MCAMD_COMPACT_BELOW 48
+#endif
+constexpr uint32_t kPool = MCAMD_POOL;                       // points per group (a group is one task of the kernels)
+constexpr uint32_t kCompactBelow = MCAMD_COMPACT_BELOW;      // hand over when this many lanes or fewer still run
 constexpr uint32_t kSurvivorCap = kWave + kCompactBelow;     // at most 63 parked + one hand-over
 
 constexpr int32_t kNoPath = 0x7fffffff;

@@ -13,7 +13,11 @@ Tolerances (stated here, used below):
   * prices vs closed form: |price - BS| <= 4 SE ("within 1e-4" is reported by
     bench.py, it is not statistically reachable at these path counts)."""
 import importlib
+import json
 import math
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -940,3 +944,19 @@ def test_full_size_config3_properties(ctx):
     assert torch.isfinite(rows[::50]).all()
     del traj
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("tool,seconds", [("fuzz_nmc.py", 6), ("fuzz_window_price.py", 6)])
+def test_differential_fuzzers_stay_clean(tool, seconds):
+    # a few seconds of the differential fuzzers of tools/ (compacting kernels against the non-compacting ones; thousands
+    # of random jobs), with a seed of the day so that successive rounds cover different cases; the long runs are in
+    # profiles/r02_fuzz_*.json
+    import datetime
+    seed = int(datetime.date.today().strftime("%Y%m%d"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", tool), "--seconds", str(seconds), "--seed", str(seed)],
+                         capture_output=True, text=True, timeout=300)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, (out.stdout[-1500:], out.stderr[-1500:])
+    rep = json.loads(lines[-1])
+    assert rep["n_failures"] == 0 and rep["cases"] > 50, rep

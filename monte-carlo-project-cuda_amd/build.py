@@ -44,7 +44,8 @@ def build_id(extra=()) -> str:
             h.update(name.encode() + b"\0" + f.read())
     with open(os.path.join(ROOT, "include", "mcamd.h"), "rb") as f:
         h.update(f.read())
-    h.update(" ".join(_flags(extra)[:3]).encode())
+    # every flag that can change the device code (include paths are machine-dependent and carry no code)
+    h.update(" ".join(f for f in _flags(extra) if not f.startswith("-I")).encode())
     return h.hexdigest()[:16]
 
 
@@ -81,19 +82,31 @@ def build(force: bool = False, extra_flags=(), jobs: int = 6) -> str:
     return LIB
 
 
-def refresh_slot_counts(extra=()) -> None:
+def refresh_slot_counts(extra=()) -> bool:
     """Recounts the VALU issue slots of the shipped inner loops (tools/count_valu_slots.py -> profiles/valu_slots.json)
-    whenever the committed counts were taken from other sources than the library just built."""
+    whenever the committed counts were taken from other sources than the library just built.  Best effort: the tool
+    is a heuristic reader of the compiler's assembly, and a failure there must not fail a build whose library has
+    already linked — the counts then keep their old build id, which bench.py detects (roofline.frac null, both ids
+    reported).  Returns whether the counts describe this build."""
     import json
+    import sys
     path = os.path.join(ROOT, "profiles", "valu_slots.json")
     try:
         with open(path) as f:
             if json.load(f).get("build_id") == build_id(extra):
-                return
+                return True
     except (OSError, ValueError):
         pass
-    subprocess.check_call([os.environ.get("PYTHON", "python3"), os.path.join(ROOT, "tools", "count_valu_slots.py")],
-                          stdout=subprocess.DEVNULL)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "count_valu_slots.py"), "--hipcc", hipcc()]
+    for f in extra:
+        cmd += ["--extra-flag=" + f]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+        return True
+    except (subprocess.CalledProcessError, OSError) as e:
+        print(f"build.py: warning: VALU slot recount failed ({e}); profiles/valu_slots.json keeps its old build id and "
+              "bench.py will report roofline.frac as null", file=sys.stderr)
+        return False
 
 
 if __name__ == "__main__":

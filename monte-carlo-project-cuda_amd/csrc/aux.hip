@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
 #pragma unroll
                     for (int e = 0; e < V; ++e) {
                         // a dead vector multiplies the price by 2^0
-                        const T x = live ? __builtin_fma(zz[i][e], c.vol, c.drift) : T(0);
+                        const T x = live ? fma_t(zz[i][e], c.vol, c.drift) : T(0);
                         ps.step(x, m);
                         if (WINDOW) count += (live && c.B > ps.value(m)) ? 1 : 0;
                     }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void from_normals_kernel(ArrayArgs<T> a, do
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (my_path < a.n_local) {
                     for (uint32_t j = 0; j < n_cols; ++j) {
-                        ps.step(__builtin_fma(tile[wave][lane][j], c.vol, c.drift), m);
+                        ps.step(fma_t(tile[wave][lane][j], c.vol, c.drift), m);
                         if (WINDOW) count += (c.B > ps.value(m)) ? 1 : 0;
                     }
                 }

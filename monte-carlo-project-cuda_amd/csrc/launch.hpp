@@ -41,7 +41,7 @@ uint32_t array_grid(uint64_t n_local);
 hipError_t launch_from_normals(const PathJob &job, const void *d_normals, void *d_payoffs, double *d_partials,
                                uint32_t grid, hipStream_t stream);
 
-// sums n_records records of record_doubles (2, 3 or 5) doubles into d_out[0..record_doubles)
+// sums n_records records of record_doubles (2, 4 = kNmcRecord, or 5) doubles into d_out[0..record_doubles)
 // n_value >= 0: also zero-fill d_out[record_doubles..5) and write d_out[5] = n_value (the 6-double stats layout)
 hipError_t launch_final_reduce(const double *d_partials, uint32_t n_records, int record_doubles, double *d_out,
                                hipStream_t stream, double n_value = -1.0);
@@ -59,7 +59,8 @@ struct NmcJob {
     uint64_t n_points;       // n_local * n_steps
     uint32_t compute_units;  // of the device the job runs on (sizes the persistent grid of the wave-per-point kernel)
 };
-// the nested-MC kernels write 3-double block records: {sum of point prices, sum of squares, wave-steps executed}
+// the nested-MC kernels write 4-double block records: {sum of point prices, sum of their squares, wave-steps executed
+// (x 64 = lane-steps of work), lane-steps of paths whose window was still open}
 constexpr int kNmcRecord = 4;
 uint32_t nmc_grid(const NmcJob &job, int variant);
 // d_queue: one zeroed 64-bit word (the wave-per-point kernel's task counter; the launcher zeroes it on `stream`)

@@ -383,7 +383,7 @@ struct Sample {
     T pay;   // payoff (mean of the pair with ANTI)
     T ctrl;  // terminal price S_T (mean of the pair with ANTI); with WINDOW, the price where the loop stopped
     uint32_t steps_run;  // steps the wavefront executed (wave-uniform): n_sim unless the window let it stop early
-    uint32_t live_steps; // of steps_run x 64 lane-steps, those of lanes whose window was still open (wave-uniform, WINDOW only)
+    uint64_t live_steps; // of steps_run x 64 lane-steps, those of lanes whose window was still open (wave-uniform, WINDOW only)
 };
 
 // lanes of the wavefront that can still be paid (barrier count not beyond P2); 0: the window has closed for all
@@ -410,7 +410,7 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
     bool rem_live = true;
     // lanes entering the next block with an open window (EARLY only; every active lane at the start)
     uint32_t open_lanes = EARLY ? static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(true))) : 0u;
-    uint32_t live_steps = 0;
+    uint64_t live_steps = 0;   // up to 64 x n_sim
     // LOGSPACE: WINDOW ? ln(St/S_start) so far : sum of the normals so far (the twin's sum is its negative)
     T acc = WINDOW ? log_start : T(0), acc2 = acc;
     if (LOGSPACE) {
@@ -499,7 +499,7 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
     }
     Sample<T> out;
     out.steps_run = steps_run;
-    out.live_steps = live_steps + ((rem && rem_live) ? open_lanes * rem : 0u);
+    out.live_steps = live_steps + ((rem && rem_live) ? static_cast<uint64_t>(open_lanes) * rem : 0ull);
     out.pay = payoff<T, WINDOW>(St, count, c);
     out.ctrl = St;
     if (ANTI) {
@@ -512,8 +512,8 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
 template <typename T, bool WINDOW, bool LOGSPACE>
 __device__ __forceinline__ T simulate_path(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &seed,
                                            uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
-                                           T log_start = T(0), uint32_t *steps_run = nullptr,
-                                           uint32_t *live_steps = nullptr)
+                                           T log_start = T(0), uint64_t *steps_run = nullptr,
+                                           uint64_t *live_steps = nullptr)
 {
     const Sample<T> s = simulate_sample<T, WINDOW, LOGSPACE, false>(c, m, seed, subsequence, St, count, n_sim, log_start);
     if (steps_run) *steps_run += s.steps_run;

@@ -117,7 +117,7 @@ __device__ __forceinline__ void price_group(const NmcArgs<T> &a, const StepConst
             const T St0 = prices[idx];
             const uint64_t point_id = (a.path_offset + path0 + s) * a.n_steps + step;
             double acc = 0.0;
-            uint32_t steps_run = 0;
+            uint64_t steps_run = 0;   // 64-bit: n_inner / 64 passes of up to 2^32 steps each
             for (uint32_t j = lane; j < a.n_inner; j += kWave)
                 acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(c, m, key, point_id * a.n_inner + j, St0, 0,
                                                                                remaining, T(0), &steps_run));
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
         const uint32_t remaining = a.n_steps - (step + 1);
         const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
         double acc = 0.0;
-        uint32_t steps_run = 0, live_steps = 0;
+        uint64_t steps_run = 0, live_steps = 0;   // 64-bit: a point may hold more than 2^32 lane-steps
         if (!WINDOW || cnt0 <= c.P2) {
             const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
             for (uint32_t j = threadIdx.x; j < a.n_inner; j += kBlock)
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
         // wave-steps and live lane-steps: each wavefront's first lane runs every pass that wavefront makes
         const bool first_lane = (threadIdx.x & (kWave - 1)) == 0;
         double pt[3] = {acc, first_lane ? static_cast<double>(steps_run) : 0.0,
-                        first_lane ? static_cast<double>(WINDOW ? live_steps : 0u) : 0.0};
+                        first_lane ? static_cast<double>(WINDOW ? live_steps : 0ull) : 0.0};
         block_sumN<kBlock, 3>(pt);
         acc = pt[0];
         const double work = pt[1];

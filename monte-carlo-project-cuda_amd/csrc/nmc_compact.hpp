@@ -33,6 +33,11 @@ constexpr uint32_t kPool = MCAMD_POOL;                       // points per group
 constexpr uint32_t kCompactBelow = MCAMD_COMPACT_BELOW;      // hand over when this many lanes or fewer still run
 constexpr uint32_t kSurvivorCap = kWave + kCompactBelow;     // at most 63 parked + one hand-over
 
+// the loops below rely on these: kCompactBelow >= kWave would make every non-last resumed batch hand over at once and
+// re-park all of its lanes (the resume loop never ends); the pool's descriptors are written by lanes 0..kPool-1
+static_assert(kCompactBelow >= 1 && kCompactBelow < static_cast<uint32_t>(kWave), "MCAMD_COMPACT_BELOW must be in [1, 64)");
+static_assert(kPool >= 1 && kPool <= static_cast<uint32_t>(kWave), "MCAMD_POOL must be in [1, 64]");
+
 constexpr int32_t kNoPath = 0x7fffffff;
 
 // One wavefront's parked paths (structure of arrays: lane-consecutive slots, conflict-free).

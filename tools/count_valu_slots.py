@@ -96,12 +96,19 @@ def measured_costs():
     return cost
 
 
-def asm_of(src: str) -> str:
+def build_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mcamd_build", os.path.join(ROOT, "monte-carlo-project-cuda_amd", "build.py"))
+    bmod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bmod)
+    return bmod
+
+
+def asm_of(src: str, hipcc: str, flags) -> str:
+    """Assembly of one kernel source, compiled with the library's own compiler and flags (build.py)."""
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                               "-I" + CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out],
-                              stderr=subprocess.DEVNULL)
+        subprocess.check_call([hipcc, *flags, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out])
         return open(out).read()
 
 
@@ -159,12 +166,21 @@ KERNELS = {
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hipcc", default=None, help="compiler (default: the one build.py finds)")
+    ap.add_argument("--extra-flag", action="append", default=[], help="extra compile flag of a variant build (repeatable)")
+    args = ap.parse_args()
+    bmod = build_module()
+    hipcc = args.hipcc or bmod.hipcc()
+    extra = tuple(args.extra_flag)
+    flags = [f for f in bmod._flags(extra) if f != "-fPIC"]
     cache, result, md = {}, {}, ["# VALU issue slots per path-step (gfx950 ISA of the shipped inner loops)\n",
                                  "Generated by tools/count_valu_slots.py; weights from profiles/r01_valu_issue_costs.json.\n"]
     cost = measured_costs()
     for key, spec_ in KERNELS.items():
         src, sym, steps = spec_[:3]
-        asm = cache.setdefault(src, asm_of(src))
+        asm = cache[src] if src in cache else cache.setdefault(src, asm_of(src, hipcc, flags))
         lines_ = step_loop(asm, sym, spec_[3] if len(spec_) > 3 else "shortest")
         # an instruction is keyed by its opcode, plus "(sgpr)" when a full-rate opcode reads a scalar register
         keyed = [(l.split()[0] + (" (sgpr src)" if cycles(l.split()[0]) == 2 and reads_sgpr(l) else ""), line_cycles(l))
@@ -191,11 +207,7 @@ def main():
         for op, n in sorted(cnt.items(), key=lambda kv: (-cost_of[kv[0]] * kv[1], kv[0])):
             md.append(f"| {n} | `{op}` | {cost_of[op]} |")
     # the id of the sources these counts were taken from (== mcamd_build_id() of a library built from them)
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("mcamd_build", os.path.join(ROOT, "monte-carlo-project-cuda_amd", "build.py"))
-    bmod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bmod)
-    result["build_id"] = bmod.build_id()
+    result["build_id"] = bmod.build_id(extra)
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "profiles", "valu_slots.json"), "w") as f:
         json.dump(result, f, indent=1)

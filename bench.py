@@ -456,7 +456,15 @@ def main(argv=None):
                 r_o = ctx.simulate_trajectories(nmc["opt"], sim_o, nmc["traj"], nmc["cnt"])
                 res = ctx.nmc_inner(nmc["opt"], sim_i, nmc["traj"], nmc["cnt"], nmc["out"], variant=nmc["variant"])
                 outer_ms = r_o.kernel_ms
-            nmc_runs.append((res.kernel_ms, outer_ms, res.work_steps, res.live_steps))
+            work, live, k_ms_local = res.work_steps, res.live_steps, res.kernel_ms
+            if world > 1:
+                # the one collective of the path: the shard's statistics record (sum and count of its point prices,
+                # with the work counters riding along), summed over the ranks; per-point prices stay on their GPU
+                s, s2, n, work, live = sharding.allreduce_vector([res.sum, res.sumsq, res.n, work, live], device=coll_device)
+                res = capi.finalize_nmc_stats([s, s2, work / 64.0, live, 0.0, n])
+                res.kernel_ms = k_ms_local
+            nmc_runs.append((k_ms_local, outer_ms, work, live))   # work / live: whole job (all ranks) per pass
+            return res, res
         if world > 1:
             s, s2, n = sharding.allreduce_stats(res.sum, res.sumsq, res.n, device=coll_device)
             fin = capi.finalize(s, s2, n, opt.r, opt.T)
@@ -527,7 +535,7 @@ def main(argv=None):
             line["live_inner_path_steps_per_pass"] = live
             line["lane_efficiency"] = live / work if work else None
             line["executed_inner_path_steps_per_s"] = work * args.steps / elapsed
-            line["european_window_inner_path_steps"] = per_gpu * n_inner * (n_steps * (n_steps - 1) // 2)
+            line["european_window_inner_path_steps"] = n_total * n_inner * (n_steps * (n_steps - 1) // 2)
             line["inner_kernel_ms"] = k_ms
             line["outer_kernel_ms"] = o_ms
             line["mean_point_price"] = fin.price
@@ -535,7 +543,8 @@ def main(argv=None):
             # imbalance: kernel time against the time the executed steps would take at the in-register kernel's rate
             key = "nmc_wave_f64_window"
             line["roofline"] = valu_roofline(W, stale, key, f"nmc_{args.nmc_strategy}_kernel<double,window>",
-                                             work / (k_ms / 1e3), extra={"work": "64 lanes x steps each wavefront ran; W is the loop over fresh paths, resumed batches run the dearer loop",
+                                             work / world / (k_ms / 1e3),   # per GPU: rank 0's kernel time, 1/world of the job's steps
+                                             extra={"work": "64 lanes x steps each wavefront ran; W is the loop over fresh paths, resumed batches run the dearer loop",
                                                     "valu_slots_resumed_batches": W.get("nmc_wave_f64_window_resumed")})
         if wl != "nmc":
             line.update({"price": fin.price, "std_err": fin.std_err, "ci95": [fin.ci_lo, fin.ci_hi],

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MCAMD_ABI_VERSION 4
+#define MCAMD_ABI_VERSION 5
 
 /* status codes */
 #define MCAMD_OK 0
@@ -235,7 +235,11 @@ int mcamd_reduce_sum(mcamd_ctx *ctx, const void *d_in, uint64_t n, int precision
  * discount exp(-rT).  d_prices / d_counts are what mcamd_simulate_trajectories wrote (same layout
  * argument); d_point_prices receives one value of the path precision per point in that layout.
  * Inner stream: seed = sim->seed, subsequence = global_point_id * n_paths_inner + j with
- * global_point_id = global_path * n_steps + step.
+ * global_point_id = global_path * n_steps + step (global_path = path_offset + local path): a shard of a job prices
+ * its points from the same streams as the whole job.  WAVE_PER_POINT pools the continuation paths of 8 outer paths
+ * whose GLOBAL ids share id / 8, so a point's price is bit-identical under any sharding wherever its pool lies
+ * inside the shard, and differs by fp64 summation order only in a shard's partial first / last pool;
+ * BLOCK_PER_POINT and the window-less job are bit-identical under any sharding.
  * Replaces compute_nmc_one_block_per_point / compute_nmc_optimal, inc/nmc.cuh:12-108,280-386.
  * res->sum / n: sum and count of the per-point prices (the wrappers' scalar diagnostic,
  * inc/wrappers.cuh:185-189,316-321). */
@@ -251,6 +255,25 @@ int mcamd_nmc_inner(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
 int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, uint64_t outer_seed, int layout,
                     void *d_prices, int32_t *d_counts, void *d_point_prices, mcamd_result *res);
 
+/* Asynchronous forms of the trajectory store and the nested-MC calls, as mcamd_price_paths_enqueue: the simulation
+ * kernel and the final reduction are enqueued on the context's stream, nothing waits on the host.  d_stats (device,
+ * >= 6 doubles) receives
+ *   store:      {sum, sumsq, 0, 0, 0, n}                              -> mcamd_finalize_stats
+ *   nested MC:  {sum of point prices, sum of their squares, wave-steps executed, live lane-steps, 0, n points}
+ *                                                                     -> mcamd_finalize_nmc_stats
+ * so ONE all-reduce of 6 doubles carries a shard whichever call produced it.  The output arrays are complete when
+ * the stream reaches the point after the call.  mcamd_enqueued_kernel_ms covers these calls too.  New (the
+ * reference is fully synchronous). */
+int mcamd_simulate_trajectories_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout,
+                                        void *d_traj, int32_t *d_counts, void *d_payoffs, double *d_stats);
+int mcamd_nmc_inner_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout, int variant,
+                            const void *d_prices, const int32_t *d_counts, void *d_point_prices, double *d_stats);
+int mcamd_nmc_fused_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, uint64_t outer_seed,
+                            int layout, void *d_prices, int32_t *d_counts, void *d_point_prices, double *d_stats);
+/* Host: sum / sumsq / n / price (= mean point price) / work_steps / live_steps of a (possibly all-reduced) nested-MC
+ * statistics record copied back from the device. */
+int mcamd_finalize_nmc_stats(const double stats[6], mcamd_result *res);
+
 /* ---- single-process multi-GPU (the shape of the reference's own main(): one host process) ----
  * A group owns one context per device and an RCCL communicator clique over them (ncclCommInitAll; RCCL is loaded
  * with dlopen on first use).  mcamd_group_price_paths splits [path_offset, path_offset + n_paths_local) of the job
@@ -264,6 +287,31 @@ int mcamd_group_create(int n_devices, const int *devices, mcamd_group **group);
 int mcamd_group_destroy(mcamd_group *group);
 int mcamd_group_size(mcamd_group *group, int *n_devices);
 int mcamd_group_price_paths(mcamd_group *group, const mcamd_option *opt, const mcamd_sim *sim, mcamd_result *res);
+
+/* The other two shards of SURVEY 8e: "trajectory-store mode shards the [step][path] buffer by path columns per GPU; no
+ * exchange" and "NMC shards by outer path; per-point prices stay on the owning GPU".  The reference's store and
+ * nested-MC hosts are single-process C++ (inc/trajectories.cuh:273-351, inc/wrappers.cuh:128-340), which is the shape
+ * these calls serve.  Device i of the group works on the shard mcamd_group_shard reports for it (contiguous global
+ * path ids, sizes differing by at most one) and writes into the caller's buffers ON THAT DEVICE: d_traj[i], d_counts[i],
+ * d_payoffs[i], d_prices[i], d_point_prices[i] are arrays of n_devices device pointers, each sized for its own shard
+ * (shape rules of the single-device calls with n_paths_local = the shard's; a NULL array = the single-device call's
+ * NULL; entries of empty shards are ignored).  mcamd_group_ctx hands out device i's context for mcamd_device_malloc /
+ * mcamd_memcpy_*.  All devices run concurrently (the *_enqueue forms); the only exchange is ONE ncclAllReduce of the
+ * 6-double statistics record; res is finalized from the reduced record (store: price / SE / CI of the whole job;
+ * nested MC: sum / mean / count of all point prices, executed and live lane-steps), kernel_ms = the slowest device's
+ * simulation kernel.  Results equal the single-device call's: stored columns and per-point prices as documented at
+ * mcamd_nmc_inner (bit-identical outside a shard's partial edge pools), statistics up to fp64 summation order. */
+int mcamd_group_ctx(mcamd_group *group, int i, mcamd_ctx **ctx);
+int mcamd_group_shard(mcamd_group *group, const mcamd_sim *sim, int i, uint64_t *path_offset, uint64_t *n_paths_local);
+int mcamd_group_simulate_trajectories(mcamd_group *group, const mcamd_option *opt, const mcamd_sim *sim, int layout,
+                                      void *const *d_traj, int32_t *const *d_counts, void *const *d_payoffs,
+                                      mcamd_result *res);
+int mcamd_group_nmc_inner(mcamd_group *group, const mcamd_option *opt, const mcamd_sim *sim, int layout, int variant,
+                          const void *const *d_prices, const int32_t *const *d_counts, void *const *d_point_prices,
+                          mcamd_result *res);
+int mcamd_group_nmc_fused(mcamd_group *group, const mcamd_option *opt, const mcamd_sim *sim, uint64_t outer_seed,
+                          int layout, void *const *d_prices, int32_t *const *d_counts, void *const *d_point_prices,
+                          mcamd_result *res);
 
 /* Host: discount + mean + standard error + 95% CI from (sum, sumsq, n) — after an all-reduce
  * over shards, or directly.  Fills price/std_err/ci_* (and copies sum/sumsq/n) in *res. */

@@ -25,7 +25,9 @@ EXPORTS = [
     "mcamd_get_device_info", "mcamd_device_malloc", "mcamd_device_free", "mcamd_memcpy_to_host",
     "mcamd_memcpy_to_device", "mcamd_price_paths", "mcamd_price_paths_enqueue", "mcamd_enqueued_kernel_ms",
     "mcamd_finalize_stats", "mcamd_group_create", "mcamd_group_destroy", "mcamd_group_size",
-    "mcamd_group_price_paths", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
+    "mcamd_group_price_paths", "mcamd_group_ctx", "mcamd_group_shard", "mcamd_group_simulate_trajectories",
+    "mcamd_group_nmc_inner", "mcamd_group_nmc_fused", "mcamd_simulate_trajectories_enqueue", "mcamd_nmc_inner_enqueue",
+    "mcamd_nmc_fused_enqueue", "mcamd_finalize_nmc_stats", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
     "mcamd_generate_normals", "mcamd_reduce_sum", "mcamd_nmc_inner", "mcamd_nmc_fused", "mcamd_finalize", "mcamd_finalize_cv", "mcamd_cnd_f32",
     "mcamd_bs_call_f32", "mcamd_bs_call_f64",
 ]
@@ -103,6 +105,17 @@ def load() -> C.CDLL:
     L.mcamd_group_price_paths.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), C.POINTER(Result)]
     L.mcamd_simulate_trajectories.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, vp, vp, vp,
                                               C.POINTER(Result)]
+    L.mcamd_simulate_trajectories_enqueue.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, vp, vp, vp, vp]
+    L.mcamd_nmc_inner_enqueue.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, i32, vp, vp, vp, vp]
+    L.mcamd_nmc_fused_enqueue.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), u64, i32, vp, vp, vp, vp]
+    L.mcamd_finalize_nmc_stats.argtypes = [C.POINTER(f64), C.POINTER(Result)]
+    pvp = C.POINTER(vp)
+    L.mcamd_group_ctx.argtypes = [vp, i32, C.POINTER(vp)]
+    L.mcamd_group_shard.argtypes = [vp, C.POINTER(Sim), i32, C.POINTER(u64), C.POINTER(u64)]
+    L.mcamd_group_simulate_trajectories.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, pvp, pvp, pvp,
+                                                    C.POINTER(Result)]
+    L.mcamd_group_nmc_inner.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, i32, pvp, pvp, pvp, C.POINTER(Result)]
+    L.mcamd_group_nmc_fused.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), u64, i32, pvp, pvp, pvp, C.POINTER(Result)]
     L.mcamd_price_from_normals.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), vp, vp, C.POINTER(Result)]
     L.mcamd_generate_normals.argtypes = [vp, u64, u64, i32, vp, C.POINTER(f32)]
     L.mcamd_reduce_sum.argtypes = [vp, vp, u64, i32, i32, C.POINTER(f64), C.POINTER(f32)]
@@ -166,6 +179,13 @@ def finalize_stats(stats6, r, T, control_variate=False) -> Result:
     res = Result()
     arr = (C.c_double * 6)(*[float(x) for x in stats6])
     _check(load().mcamd_finalize_stats(arr, r, T, int(control_variate), C.byref(res)))
+    return res
+
+
+def finalize_nmc_stats(stats6) -> Result:
+    res = Result()
+    arr = (C.c_double * 6)(*[float(x) for x in stats6])
+    _check(load().mcamd_finalize_nmc_stats(arr, C.byref(res)))
     return res
 
 
@@ -242,6 +262,20 @@ class Context:
                                                    _ptr(counts), _ptr(payoffs), C.byref(res)))
         return res
 
+    def simulate_trajectories_enqueue(self, opt: Option, sim: Sim, traj, counts, payoffs, stats, layout=STEP_MAJOR) -> None:
+        _check(self._L.mcamd_simulate_trajectories_enqueue(self._h, C.byref(opt), C.byref(sim), layout, _ptr(traj),
+                                                           _ptr(counts), _ptr(payoffs), _ptr(stats)))
+
+    def nmc_inner_enqueue(self, opt: Option, sim: Sim, prices, counts, point_prices, stats, layout=STEP_MAJOR,
+                          variant=NMC_WAVE_PER_POINT) -> None:
+        _check(self._L.mcamd_nmc_inner_enqueue(self._h, C.byref(opt), C.byref(sim), layout, variant, _ptr(prices),
+                                               _ptr(counts), _ptr(point_prices), _ptr(stats)))
+
+    def nmc_fused_enqueue(self, opt: Option, sim: Sim, outer_seed: int, prices, counts, point_prices, stats,
+                          layout=STEP_MAJOR) -> None:
+        _check(self._L.mcamd_nmc_fused_enqueue(self._h, C.byref(opt), C.byref(sim), outer_seed, layout, _ptr(prices),
+                                               _ptr(counts), _ptr(point_prices), _ptr(stats)))
+
     def price_from_normals(self, opt: Option, sim: Sim, normals, payoffs=None) -> Result:
         res = Result()
         _check(self._L.mcamd_price_from_normals(self._h, C.byref(opt), C.byref(sim), _ptr(normals), _ptr(payoffs),
@@ -301,4 +335,36 @@ class Group:
     def price_paths(self, opt: Option, sim: Sim) -> Result:
         res = Result()
         _check(self._L.mcamd_group_price_paths(self._h, C.byref(opt), C.byref(sim), C.byref(res)))
+        return res
+
+    def shard(self, sim: Sim, i: int):
+        """(first global path id, number of paths) device i of the group works on for this job."""
+        lo, n = C.c_uint64(0), C.c_uint64(0)
+        _check(self._L.mcamd_group_shard(self._h, C.byref(sim), i, C.byref(lo), C.byref(n)))
+        return lo.value, n.value
+
+    @staticmethod
+    def _ptrs(per_device):
+        """array of one device pointer per device (None: no such output)"""
+        if per_device is None:
+            return None
+        return (C.c_void_p * len(per_device))(*[None if t is None else t.data_ptr() for t in per_device])
+
+    def simulate_trajectories(self, opt: Option, sim: Sim, traj, counts=None, payoffs=None, layout=STEP_MAJOR) -> Result:
+        res = Result()
+        _check(self._L.mcamd_group_simulate_trajectories(self._h, C.byref(opt), C.byref(sim), layout, self._ptrs(traj),
+                                                         self._ptrs(counts), self._ptrs(payoffs), C.byref(res)))
+        return res
+
+    def nmc_inner(self, opt: Option, sim: Sim, prices, counts, point_prices, layout=STEP_MAJOR,
+                  variant=NMC_WAVE_PER_POINT) -> Result:
+        res = Result()
+        _check(self._L.mcamd_group_nmc_inner(self._h, C.byref(opt), C.byref(sim), layout, variant, self._ptrs(prices),
+                                             self._ptrs(counts), self._ptrs(point_prices), C.byref(res)))
+        return res
+
+    def nmc_fused(self, opt: Option, sim: Sim, outer_seed: int, prices, counts, point_prices, layout=STEP_MAJOR) -> Result:
+        res = Result()
+        _check(self._L.mcamd_group_nmc_fused(self._h, C.byref(opt), C.byref(sim), outer_seed, layout, self._ptrs(prices),
+                                             self._ptrs(counts), self._ptrs(point_prices), C.byref(res)))
         return res

@@ -236,6 +236,104 @@ void finalize_into(double sum, double sumsq, uint64_t n, double r, double T, mca
     res->ci_hi = res->price + 1.959963984540054 * se;
 }
 
+// argument checks and job of the trajectory store (shared by the synchronous call and the enqueue form)
+int prepare_store(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout, const void *d_traj,
+                         const int32_t *d_counts, mcamd::PathJob *job)
+{
+    mcamd_result dummy;
+    if (int rc = check_common(ctx, opt, sim, &dummy)) return rc;
+    if (sim->flags & (MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
+        return fail(MCAMD_ERR_INVALID, "variance-reduction flags apply to mcamd_price_paths only");
+    if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
+        return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
+    if (sim->n_paths_local == 0) return MCAMD_OK;
+    if (!d_traj) return fail(MCAMD_ERR_INVALID, "d_traj is NULL");
+    *job = make_job(opt, sim);
+    if (d_counts && !job->window) {
+        // counts requested for a European payoff: count against B but let every count pay
+        job->window = true;
+        job->P1 = INT32_MIN;
+        job->P2 = INT32_MAX;
+    }
+    return MCAMD_OK;
+}
+
+// argument checks and job of the nested-MC calls (inner stage and fused; shared by the synchronous calls and the
+// enqueue forms).  fused: d_prices / d_counts are outputs and outer_seed must differ from the inner seed.
+int prepare_nmc(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout, int variant, bool fused,
+                       uint64_t outer_seed, const void *d_prices, const int32_t *d_counts, const void *d_point_prices,
+                       mcamd::NmcJob *job)
+{
+    mcamd_result dummy;
+    if (int rc = check_common(ctx, opt, sim, &dummy)) return rc;
+    if (sim->flags & (MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
+        return fail(MCAMD_ERR_INVALID, "variance-reduction flags apply to mcamd_price_paths only");
+    if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
+        return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
+    if (!fused && variant != MCAMD_NMC_WAVE_PER_POINT && variant != MCAMD_NMC_BLOCK_PER_POINT)
+        return fail(MCAMD_ERR_INVALID, "unknown nested-MC variant %d", variant);
+    if (opt->Tk != 0) return fail(MCAMD_ERR_INVALID, "nested MC expects outer trajectories stored from step 0 (Tk = 0)");
+    if (fused && outer_seed == sim->seed)
+        return fail(MCAMD_ERR_INVALID, "outer_seed must differ from the inner seed (sim->seed): equal seeds would make "
+                                       "outer path p and inner path p draw the same Philox stream");
+    if (sim->n_paths_inner == 0) return fail(MCAMD_ERR_INVALID, "n_paths_inner must be >= 1");
+    // inner path j of point q draws Philox subsequence q * n_paths_inner + j, q = global_path * n_steps + step: the
+    // largest one of the shard must fit 64 bits
+    const long double top = static_cast<long double>(sim->path_offset + sim->n_paths_local) * sim->n_steps * sim->n_paths_inner;
+    if (top >= 18446744073709551615.0L)
+        return fail(MCAMD_ERR_INVALID, "(path_offset + n_paths_local) * n_steps * n_paths_inner overflows the 64-bit "
+                                       "Philox subsequence");
+    if (sim->n_paths_local == 0) return MCAMD_OK;
+    if (!d_prices || !d_point_prices) return fail(MCAMD_ERR_INVALID, "d_prices and d_point_prices must be non-NULL");
+    if (opt->use_window && !d_counts) return fail(MCAMD_ERR_INVALID, "bullet window needs d_counts");
+    const uint64_t n_points = sim->n_paths_local * static_cast<uint64_t>(sim->n_steps);
+    if (n_points / sim->n_steps != sim->n_paths_local) return fail(MCAMD_ERR_INVALID, "point count overflows");
+    job->path = make_job(opt, sim);
+    job->n_inner = sim->n_paths_inner;
+    job->discount = std::exp(-opt->r * opt->T);
+    job->n_points = n_points;
+    job->compute_units = ctx->compute_units;
+    return MCAMD_OK;
+}
+
+// host tail of the nested-MC calls: the scalar diagnostic of the wrappers (inc/wrappers.cuh:185-189,316-321)
+void fill_nmc_result(mcamd_result *res, uint64_t n_points, uint32_t grid)
+{
+    res->n = n_points;
+    res->price = n_points ? res->sum / static_cast<double>(n_points) : 0.0;  // mean point price (diagnostic)
+    res->grid = grid;
+    res->block = 256;
+}
+
+// Asynchronous calls: an empty shard leaves all-zero statistics, still ordered on the stream.
+int enqueue_empty(mcamd_ctx *ctx, double *d_stats)
+{
+    const uint32_t slot = static_cast<uint32_t>(ctx->n_enqueued % mcamd_ctx::kRing);
+    HIP_TRY(hipMemsetAsync(d_stats, 0, 6 * sizeof(double), ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ring0[slot], ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ring1[slot], ctx->stream));
+    ctx->n_enqueued++;
+    return MCAMD_OK;
+}
+
+// Asynchronous calls: `launch` enqueues the simulation kernel (grid blocks, one record of rec doubles each, into
+// ctx->d_partials) between a pair of ring events; the final reduce then leaves {record, zeros.., n_value} — the
+// 6-double statistics layout — in d_stats.  Nothing waits on the host.
+template <typename Launch>
+int enqueue_with_stats(mcamd_ctx *ctx, uint32_t grid, int rec, double n_value, double *d_stats, Launch launch)
+{
+    const uint32_t slot = static_cast<uint32_t>(ctx->n_enqueued % mcamd_ctx::kRing);
+    // growing the scratch buffer frees the old one: wait for work that may still read it
+    if (static_cast<uint64_t>(grid) * rec > ctx->partial_capacity) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (int rc = ensure_partials(ctx, grid, rec)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ring0[slot], ctx->stream));
+    HIP_TRY(launch());
+    HIP_TRY(hipEventRecord(ctx->ring1[slot], ctx->stream));
+    HIP_TRY(mcamd::launch_final_reduce(ctx->d_partials, grid, rec, d_stats, ctx->stream, n_value));
+    ctx->n_enqueued++;
+    return MCAMD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -432,26 +530,69 @@ int mcamd_price_paths_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mca
     if (int rc = check_common(ctx, opt, sim, &dummy)) return rc;
     if (!d_stats) return fail(MCAMD_ERR_INVALID, "d_stats is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    const uint32_t slot = static_cast<uint32_t>(ctx->n_enqueued % mcamd_ctx::kRing);
-    if (sim->n_paths_local == 0) {  // empty shard: all-zero statistics, still ordered on the stream
-        HIP_TRY(hipMemsetAsync(d_stats, 0, 6 * sizeof(double), ctx->stream));
-        HIP_TRY(hipEventRecord(ctx->ring0[slot], ctx->stream));
-        HIP_TRY(hipEventRecord(ctx->ring1[slot], ctx->stream));
-        ctx->n_enqueued++;
-        return MCAMD_OK;
-    }
+    if (sim->n_paths_local == 0) return enqueue_empty(ctx, d_stats);
     const mcamd::PathJob job = make_job(opt, sim);
     const int rec = (job.vr & 2) ? 5 : 2;
     const uint32_t grid = mcamd::price_grid(job, ctx->compute_units);
-    // growing the scratch buffer frees the old one: wait for work that may still read it
-    if (static_cast<uint64_t>(grid) * rec > ctx->partial_capacity) HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (int rc = ensure_partials(ctx, grid, rec)) return rc;
-    HIP_TRY(hipEventRecord(ctx->ring0[slot], ctx->stream));
-    HIP_TRY(mcamd::launch_price(job, ctx->compute_units, ctx->d_partials, ctx->d_queue, grid, ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->ring1[slot], ctx->stream));
-    HIP_TRY(mcamd::launch_final_reduce(ctx->d_partials, grid, rec, d_stats, ctx->stream,
-                                       static_cast<double>(sim->n_paths_local)));
-    ctx->n_enqueued++;
+    return enqueue_with_stats(ctx, grid, rec, static_cast<double>(sim->n_paths_local), d_stats, [&] {
+        return mcamd::launch_price(job, ctx->compute_units, ctx->d_partials, ctx->d_queue, grid, ctx->stream);
+    });
+}
+
+int mcamd_simulate_trajectories_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout,
+                                        void *d_traj, int32_t *d_counts, void *d_payoffs, double *d_stats)
+{
+    mcamd::PathJob job;
+    if (int rc = prepare_store(ctx, opt, sim, layout, d_traj, d_counts, &job)) return rc;
+    if (!d_stats) return fail(MCAMD_ERR_INVALID, "d_stats is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (sim->n_paths_local == 0) return enqueue_empty(ctx, d_stats);
+    const uint32_t grid = mcamd::store_grid(job.n_local, job.precision);
+    return enqueue_with_stats(ctx, grid, 2, static_cast<double>(sim->n_paths_local), d_stats, [&] {
+        return mcamd::launch_store(job, layout, d_traj, d_counts, d_payoffs, ctx->d_partials, grid, ctx->stream);
+    });
+}
+
+int mcamd_nmc_inner_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout, int variant,
+                            const void *d_prices, const int32_t *d_counts, void *d_point_prices, double *d_stats)
+{
+    mcamd::NmcJob job;
+    if (int rc = prepare_nmc(ctx, opt, sim, layout, variant, false, 0, d_prices, d_counts, d_point_prices, &job)) return rc;
+    if (!d_stats) return fail(MCAMD_ERR_INVALID, "d_stats is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (sim->n_paths_local == 0) return enqueue_empty(ctx, d_stats);
+    const uint32_t grid = mcamd::nmc_grid(job, variant);
+    return enqueue_with_stats(ctx, grid, mcamd::kNmcRecord, static_cast<double>(job.n_points), d_stats, [&] {
+        return mcamd::launch_nmc_inner(job, layout, variant, d_prices, d_counts, d_point_prices, ctx->d_partials,
+                                       ctx->d_queue, grid, ctx->stream);
+    });
+}
+
+int mcamd_nmc_fused_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, uint64_t outer_seed, int layout,
+                            void *d_prices, int32_t *d_counts, void *d_point_prices, double *d_stats)
+{
+    mcamd::NmcJob job;
+    if (int rc = prepare_nmc(ctx, opt, sim, layout, 0, true, outer_seed, d_prices, d_counts, d_point_prices, &job)) return rc;
+    if (!d_stats) return fail(MCAMD_ERR_INVALID, "d_stats is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (sim->n_paths_local == 0) return enqueue_empty(ctx, d_stats);
+    const uint32_t grid = mcamd::nmc_fused_grid(job);
+    return enqueue_with_stats(ctx, grid, mcamd::kNmcRecord, static_cast<double>(job.n_points), d_stats, [&] {
+        return mcamd::launch_nmc_fused(job, outer_seed, layout, d_prices, d_counts, d_point_prices, ctx->d_partials, grid,
+                                       ctx->stream);
+    });
+}
+
+int mcamd_finalize_nmc_stats(const double stats[6], mcamd_result *res)
+{
+    if (!stats || !res) return fail(MCAMD_ERR_INVALID, "stats and res must be non-NULL");
+    zero_result(res);
+    res->sum = stats[0];
+    res->sumsq = stats[1];
+    res->work_steps = 64.0 * stats[2];   // wave-steps x 64 lanes
+    res->live_steps = stats[3];
+    res->n = static_cast<uint64_t>(std::llround(stats[5]));
+    res->price = res->n ? res->sum / static_cast<double>(res->n) : 0.0;
     return MCAMD_OK;
 }
 
@@ -482,22 +623,12 @@ int mcamd_finalize_stats(const double stats[6], double r, double T, int control_
 int mcamd_simulate_trajectories(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout,
                                 void *d_traj, int32_t *d_counts, void *d_payoffs, mcamd_result *res)
 {
-    if (int rc = check_common(ctx, opt, sim, res)) return rc;
-    if (sim->flags & (MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
-        return fail(MCAMD_ERR_INVALID, "variance-reduction flags apply to mcamd_price_paths only");
-    if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
-        return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
+    if (!res) return fail(MCAMD_ERR_INVALID, "opt, sim and res must be non-NULL");
+    mcamd::PathJob job;
+    if (int rc = prepare_store(ctx, opt, sim, layout, d_traj, d_counts, &job)) return rc;
     zero_result(res);
     if (sim->n_paths_local == 0) return MCAMD_OK;
-    if (!d_traj) return fail(MCAMD_ERR_INVALID, "d_traj is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    mcamd::PathJob job = make_job(opt, sim);
-    if (d_counts && !job.window) {
-        // counts requested for a European payoff: count against B but let every count pay
-        job.window = true;
-        job.P1 = INT32_MIN;
-        job.P2 = INT32_MAX;
-    }
     const uint32_t grid = mcamd::store_grid(job.n_local, job.precision);
     if (int rc = ensure_partials(ctx, grid)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
@@ -566,77 +697,38 @@ int mcamd_reduce_sum(mcamd_ctx *ctx, const void *d_in, uint64_t n, int precision
 int mcamd_nmc_inner(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout, int variant,
                     const void *d_prices, const int32_t *d_counts, void *d_point_prices, mcamd_result *res)
 {
-    if (int rc = check_common(ctx, opt, sim, res)) return rc;
-    if (sim->flags & (MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
-        return fail(MCAMD_ERR_INVALID, "variance-reduction flags apply to mcamd_price_paths only");
-    if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
-        return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
-    if (variant != MCAMD_NMC_WAVE_PER_POINT && variant != MCAMD_NMC_BLOCK_PER_POINT)
-        return fail(MCAMD_ERR_INVALID, "unknown nested-MC variant %d", variant);
-    if (opt->Tk != 0) return fail(MCAMD_ERR_INVALID, "nested MC expects outer trajectories stored from step 0 (Tk = 0)");
-    if (sim->n_paths_inner == 0) return fail(MCAMD_ERR_INVALID, "n_paths_inner must be >= 1");
+    if (!res) return fail(MCAMD_ERR_INVALID, "opt, sim and res must be non-NULL");
+    mcamd::NmcJob job;
+    if (int rc = prepare_nmc(ctx, opt, sim, layout, variant, false, 0, d_prices, d_counts, d_point_prices, &job)) return rc;
     zero_result(res);
     if (sim->n_paths_local == 0) return MCAMD_OK;
-    if (!d_prices || !d_point_prices) return fail(MCAMD_ERR_INVALID, "d_prices and d_point_prices must be non-NULL");
-    if (opt->use_window && !d_counts) return fail(MCAMD_ERR_INVALID, "bullet window needs d_counts");
-    const uint64_t n_points = sim->n_paths_local * static_cast<uint64_t>(sim->n_steps);
-    if (n_points / sim->n_steps != sim->n_paths_local) return fail(MCAMD_ERR_INVALID, "point count overflows");
     HIP_TRY(hipSetDevice(ctx->device));
-    mcamd::NmcJob job;
-    job.path = make_job(opt, sim);
-    job.n_inner = sim->n_paths_inner;
-    job.discount = std::exp(-opt->r * opt->T);
-    job.n_points = n_points;
-    job.compute_units = ctx->compute_units;
     const uint32_t grid = mcamd::nmc_grid(job, variant);
     if (int rc = ensure_partials(ctx, grid, mcamd::kNmcRecord)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(mcamd::launch_nmc_inner(job, layout, variant, d_prices, d_counts, d_point_prices, ctx->d_partials,
                                     ctx->d_queue, grid, ctx->stream));
     if (int rc = finish(ctx, grid, res, mcamd::kNmcRecord)) return rc;
-    res->n = n_points;
-    res->price = n_points ? res->sum / static_cast<double>(n_points) : 0.0;  // mean point price (diagnostic)
-    res->grid = grid;
-    res->block = 256;
+    fill_nmc_result(res, job.n_points, grid);
     return MCAMD_OK;
 }
 
 int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, uint64_t outer_seed, int layout,
                     void *d_prices, int32_t *d_counts, void *d_point_prices, mcamd_result *res)
 {
-    if (int rc = check_common(ctx, opt, sim, res)) return rc;
-    if (sim->flags & (MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
-        return fail(MCAMD_ERR_INVALID, "variance-reduction flags apply to mcamd_price_paths only");
-    if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
-        return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
-    if (opt->Tk != 0) return fail(MCAMD_ERR_INVALID, "nested MC simulates outer trajectories from step 0 (Tk = 0)");
-    if (outer_seed == sim->seed)
-        return fail(MCAMD_ERR_INVALID, "outer_seed must differ from the inner seed (sim->seed): equal seeds would make "
-                                       "outer path p and inner path p draw the same Philox stream");
-    if (sim->n_paths_inner == 0) return fail(MCAMD_ERR_INVALID, "n_paths_inner must be >= 1");
+    if (!res) return fail(MCAMD_ERR_INVALID, "opt, sim and res must be non-NULL");
+    mcamd::NmcJob job;
+    if (int rc = prepare_nmc(ctx, opt, sim, layout, 0, true, outer_seed, d_prices, d_counts, d_point_prices, &job)) return rc;
     zero_result(res);
     if (sim->n_paths_local == 0) return MCAMD_OK;
-    if (!d_prices || !d_point_prices) return fail(MCAMD_ERR_INVALID, "d_prices and d_point_prices must be non-NULL");
-    if (opt->use_window && !d_counts) return fail(MCAMD_ERR_INVALID, "bullet window needs d_counts");
-    const uint64_t n_points = sim->n_paths_local * static_cast<uint64_t>(sim->n_steps);
-    if (n_points / sim->n_steps != sim->n_paths_local) return fail(MCAMD_ERR_INVALID, "point count overflows");
     HIP_TRY(hipSetDevice(ctx->device));
-    mcamd::NmcJob job;
-    job.path = make_job(opt, sim);
-    job.n_inner = sim->n_paths_inner;
-    job.discount = std::exp(-opt->r * opt->T);
-    job.n_points = n_points;
-    job.compute_units = ctx->compute_units;
     const uint32_t grid = mcamd::nmc_fused_grid(job);
     if (int rc = ensure_partials(ctx, grid, mcamd::kNmcRecord)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(mcamd::launch_nmc_fused(job, outer_seed, layout, d_prices, d_counts, d_point_prices, ctx->d_partials, grid,
                                     ctx->stream));
     if (int rc = finish(ctx, grid, res, mcamd::kNmcRecord)) return rc;
-    res->n = n_points;
-    res->price = res->sum / static_cast<double>(n_points);
-    res->grid = grid;
-    res->block = 256;
+    fill_nmc_result(res, job.n_points, grid);
     return MCAMD_OK;
 }
 

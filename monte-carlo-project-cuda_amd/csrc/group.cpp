@@ -107,6 +107,64 @@ void drain(mcamd_group *g)
     }
 }
 
+// device i's shard of [path_offset, path_offset + n_paths_local): contiguous, sizes differ by at most one
+mcamd_sim shard_of(const mcamd_sim &sim, int R, int i)
+{
+    const uint64_t base = sim.n_paths_local / R, rem = sim.n_paths_local % R;
+    mcamd_sim s = sim;
+    s.path_offset = sim.path_offset + static_cast<uint64_t>(i) * base + (static_cast<uint64_t>(i) < rem ? i : rem);
+    s.n_paths_local = base + (static_cast<uint64_t>(i) < rem ? 1 : 0);
+    return s;
+}
+
+// The shape every group call shares: device i enqueues its shard (enqueue(i, shard) -> one of the *_enqueue entry
+// points, which leaves a 6-double statistics record in g->d_stats[i]), then the one collective of the path sums the
+// records over the devices, every device is waited for, and the reduced record comes back to the host.
+template <typename Enqueue>
+int run_sharded(mcamd_group *g, const mcamd_sim *sim, double (&stats)[8], float *kernel_ms, Enqueue enqueue)
+{
+    const int R = static_cast<int>(g->devices.size());
+    for (int i = 0; i < R; ++i) {
+        // asynchronous: every device starts its shard before any host wait
+        if (int rc = enqueue(i, shard_of(*sim, R, i))) {
+            const std::string why = mcamd_last_error();
+            drain(g);   // shards already enqueued on devices 0..i-1 must not outlive the failed call
+            return mcamd_set_error_(rc, why.c_str());
+        }
+    }
+    // A group that was started is always ended, whatever an AllReduce returned, so a failed call cannot leave
+    // RCCL's thread-local group open for the next one.
+    ncclResult_t ne = g_rccl.GroupStart();
+    if (ne == ncclSuccess) {
+        ncclResult_t first = ncclSuccess;
+        for (int i = 0; i < R && first == ncclSuccess; ++i)
+            first = g_rccl.AllReduce(g->d_stats[i], g->d_stats[i], 6, ncclDouble, ncclSum, g->comms[i], g->streams[i]);
+        const ncclResult_t end = g_rccl.GroupEnd();
+        ne = first != ncclSuccess ? first : end;
+    }
+    if (ne != ncclSuccess) {
+        drain(g);
+        return nccl_fail(ne, "ncclAllReduce");
+    }
+    hipError_t sync_err = hipSuccess;
+    for (int i = 0; i < R; ++i) {   // every device is waited for, also after one of them has failed
+        hipError_t e = hipSetDevice(g->devices[i]);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->streams[i]);
+        if (e != hipSuccess && sync_err == hipSuccess) sync_err = e;
+    }
+    if (sync_err != hipSuccess) return hip_fail(sync_err, "group synchronise");
+    *kernel_ms = 0.0f;
+    for (int i = 0; i < R; ++i) {
+        float ms = 0.0f;
+        if (int rc = mcamd_enqueued_kernel_ms(g->ctx[i], 1, &ms)) return rc;
+        *kernel_ms = std::fmax(*kernel_ms, ms);
+    }
+    hipError_t e = hipSetDevice(g->devices[0]);
+    if (e == hipSuccess) e = hipMemcpy(stats, g->d_stats[0], 6 * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "group result copy");
+    return MCAMD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -178,57 +236,100 @@ int mcamd_group_size(mcamd_group *g, int *n_devices)
     return MCAMD_OK;
 }
 
+int mcamd_group_ctx(mcamd_group *g, int i, mcamd_ctx **ctx)
+{
+    if (!g || !ctx) return mcamd_set_error_(MCAMD_ERR_INVALID, "group and ctx must be non-NULL");
+    if (i < 0 || i >= static_cast<int>(g->ctx.size())) return mcamd_set_error_(MCAMD_ERR_INVALID, "device index out of range");
+    *ctx = g->ctx[i];
+    return MCAMD_OK;
+}
+
+int mcamd_group_shard(mcamd_group *g, const mcamd_sim *sim, int i, uint64_t *path_offset, uint64_t *n_paths_local)
+{
+    if (!g || !sim || !path_offset || !n_paths_local)
+        return mcamd_set_error_(MCAMD_ERR_INVALID, "group, sim and the out-pointers must be non-NULL");
+    if (i < 0 || i >= static_cast<int>(g->ctx.size())) return mcamd_set_error_(MCAMD_ERR_INVALID, "device index out of range");
+    const mcamd_sim s = shard_of(*sim, static_cast<int>(g->devices.size()), i);
+    *path_offset = s.path_offset;
+    *n_paths_local = s.n_paths_local;
+    return MCAMD_OK;
+}
+
 int mcamd_group_price_paths(mcamd_group *g, const mcamd_option *opt, const mcamd_sim *sim, mcamd_result *res)
 {
     if (!g || !opt || !sim || !res) return mcamd_set_error_(MCAMD_ERR_INVALID, "group, opt, sim and res must be non-NULL");
-    const int R = static_cast<int>(g->devices.size());
-    // contiguous shards of [path_offset, path_offset + n_paths_local): sizes differ by at most one
-    const uint64_t base = sim->n_paths_local / R, rem = sim->n_paths_local % R;
-    for (int i = 0; i < R; ++i) {
-        mcamd_sim s = *sim;
-        s.path_offset = sim->path_offset + static_cast<uint64_t>(i) * base + (static_cast<uint64_t>(i) < rem ? i : rem);
-        s.n_paths_local = base + (static_cast<uint64_t>(i) < rem ? 1 : 0);
-        // asynchronous: every device starts its shard before any host wait
-        if (int rc = mcamd_price_paths_enqueue(g->ctx[i], opt, &s, g->d_stats[i])) {
-            const std::string why = mcamd_last_error();
-            drain(g);   // shards already enqueued on devices 0..i-1 must not outlive the failed call
-            return mcamd_set_error_(rc, why.c_str());
-        }
-    }
-    // the one collective of the path: (sum, sumsq, sum_c, sum_cc, sum_yc, n) summed over the devices.  A group
-    // that was started is always ended, whatever an AllReduce returned, so a failed call cannot leave RCCL's
-    // thread-local group open for the next one.
-    ncclResult_t ne = g_rccl.GroupStart();
-    if (ne == ncclSuccess) {
-        ncclResult_t first = ncclSuccess;
-        for (int i = 0; i < R && first == ncclSuccess; ++i)
-            first = g_rccl.AllReduce(g->d_stats[i], g->d_stats[i], 6, ncclDouble, ncclSum, g->comms[i], g->streams[i]);
-        const ncclResult_t end = g_rccl.GroupEnd();
-        ne = first != ncclSuccess ? first : end;
-    }
-    if (ne != ncclSuccess) {
-        drain(g);
-        return nccl_fail(ne, "ncclAllReduce");
-    }
     double stats[8] = {0};
     float kernel_ms = 0.0f;
-    hipError_t sync_err = hipSuccess;
-    for (int i = 0; i < R; ++i) {   // every device is waited for, also after one of them has failed
-        hipError_t e = hipSetDevice(g->devices[i]);
-        if (e == hipSuccess) e = hipStreamSynchronize(g->streams[i]);
-        if (e != hipSuccess && sync_err == hipSuccess) sync_err = e;
-    }
-    if (sync_err != hipSuccess) return hip_fail(sync_err, "group synchronise");
-    for (int i = 0; i < R; ++i) {
-        float ms = 0.0f;
-        if (int rc = mcamd_enqueued_kernel_ms(g->ctx[i], 1, &ms)) return rc;
-        kernel_ms = std::fmax(kernel_ms, ms);
-    }
-    hipError_t e = hipSetDevice(g->devices[0]);
-    if (e == hipSuccess) e = hipMemcpy(stats, g->d_stats[0], 6 * sizeof(double), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hip_fail(e, "group result copy");
+    if (int rc = run_sharded(g, sim, stats, &kernel_ms, [&](int i, const mcamd_sim &s) {
+            return mcamd_price_paths_enqueue(g->ctx[i], opt, &s, g->d_stats[i]);
+        }))
+        return rc;
     if (int rc = mcamd_finalize_stats(stats, opt->r, opt->T, (sim->flags & MCAMD_FLAG_CONTROL_VARIATE) != 0, res)) return rc;
     res->kernel_ms = kernel_ms;  // slowest device's simulation kernel
+    res->total_ms = kernel_ms;
+    res->block = 256;
+    return MCAMD_OK;
+}
+
+int mcamd_group_simulate_trajectories(mcamd_group *g, const mcamd_option *opt, const mcamd_sim *sim, int layout,
+                                      void *const *d_traj, int32_t *const *d_counts, void *const *d_payoffs,
+                                      mcamd_result *res)
+{
+    if (!g || !opt || !sim || !res) return mcamd_set_error_(MCAMD_ERR_INVALID, "group, opt, sim and res must be non-NULL");
+    if (!d_traj && sim->n_paths_local) return mcamd_set_error_(MCAMD_ERR_INVALID, "d_traj (one device pointer per device) is NULL");
+    double stats[8] = {0};
+    float kernel_ms = 0.0f;
+    if (int rc = run_sharded(g, sim, stats, &kernel_ms, [&](int i, const mcamd_sim &s) {
+            return mcamd_simulate_trajectories_enqueue(g->ctx[i], opt, &s, layout, d_traj ? d_traj[i] : nullptr,
+                                                       d_counts ? d_counts[i] : nullptr, d_payoffs ? d_payoffs[i] : nullptr,
+                                                       g->d_stats[i]);
+        }))
+        return rc;
+    if (int rc = mcamd_finalize_stats(stats, opt->r, opt->T, 0, res)) return rc;
+    res->kernel_ms = kernel_ms;
+    res->total_ms = kernel_ms;
+    res->block = 256;
+    return MCAMD_OK;
+}
+
+int mcamd_group_nmc_inner(mcamd_group *g, const mcamd_option *opt, const mcamd_sim *sim, int layout, int variant,
+                          const void *const *d_prices, const int32_t *const *d_counts, void *const *d_point_prices,
+                          mcamd_result *res)
+{
+    if (!g || !opt || !sim || !res) return mcamd_set_error_(MCAMD_ERR_INVALID, "group, opt, sim and res must be non-NULL");
+    if ((!d_prices || !d_point_prices) && sim->n_paths_local)
+        return mcamd_set_error_(MCAMD_ERR_INVALID, "d_prices and d_point_prices (one device pointer per device) must be non-NULL");
+    double stats[8] = {0};
+    float kernel_ms = 0.0f;
+    if (int rc = run_sharded(g, sim, stats, &kernel_ms, [&](int i, const mcamd_sim &s) {
+            return mcamd_nmc_inner_enqueue(g->ctx[i], opt, &s, layout, variant, d_prices ? d_prices[i] : nullptr,
+                                           d_counts ? d_counts[i] : nullptr, d_point_prices ? d_point_prices[i] : nullptr,
+                                           g->d_stats[i]);
+        }))
+        return rc;
+    if (int rc = mcamd_finalize_nmc_stats(stats, res)) return rc;
+    res->kernel_ms = kernel_ms;
+    res->total_ms = kernel_ms;
+    res->block = 256;
+    return MCAMD_OK;
+}
+
+int mcamd_group_nmc_fused(mcamd_group *g, const mcamd_option *opt, const mcamd_sim *sim, uint64_t outer_seed, int layout,
+                          void *const *d_prices, int32_t *const *d_counts, void *const *d_point_prices, mcamd_result *res)
+{
+    if (!g || !opt || !sim || !res) return mcamd_set_error_(MCAMD_ERR_INVALID, "group, opt, sim and res must be non-NULL");
+    if ((!d_prices || !d_point_prices) && sim->n_paths_local)
+        return mcamd_set_error_(MCAMD_ERR_INVALID, "d_prices and d_point_prices (one device pointer per device) must be non-NULL");
+    double stats[8] = {0};
+    float kernel_ms = 0.0f;
+    if (int rc = run_sharded(g, sim, stats, &kernel_ms, [&](int i, const mcamd_sim &s) {
+            return mcamd_nmc_fused_enqueue(g->ctx[i], opt, &s, outer_seed, layout, d_prices ? d_prices[i] : nullptr,
+                                           d_counts ? d_counts[i] : nullptr, d_point_prices ? d_point_prices[i] : nullptr,
+                                           g->d_stats[i]);
+        }))
+        return rc;
+    if (int rc = mcamd_finalize_nmc_stats(stats, res)) return rc;
+    res->kernel_ms = kernel_ms;
     res->total_ms = kernel_ms;
     res->block = 256;
     return MCAMD_OK;

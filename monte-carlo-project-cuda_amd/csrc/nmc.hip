@@ -57,29 +57,52 @@ __device__ __forceinline__ uint64_t point_index(const NmcArgs<T> &a, uint64_t ta
     return LAYOUT == MCAMD_STEP_MAJOR ? task : path * a.n_steps + step;
 }
 
-// A task of the wave-per-point and fused kernels is a GROUP: one step of kPool adjacent outer paths (the last group of
-// a step may be short).  With a window the group's continuation paths are one pool for the lane compaction of
-// nmc_compact.hpp; without one its points are simply priced one after the other.
+// A task of the wave-per-point and fused kernels is a GROUP: one step of kPool adjacent outer paths.  Groups are cut
+// at multiples of kPool of the GLOBAL path id, not of the shard's local index: group G of a step holds global paths
+// [G kPool, (G + 1) kPool), of which a shard prices the ones it owns (its first and last group may be partial).  A
+// compaction pool's schedule — and with it the summation order inside each of its points' means — depends on which
+// points share the pool, so with globally cut groups every group that lies inside a shard is priced exactly as the
+// whole job prices it: per-point prices are bit-identical under any sharding, except in a shard's partial edge groups,
+// which differ from the whole job by fp64 summation order only (each path's payoff is the same bits everywhere).
+// With a window the group's continuation paths are one pool for the lane compaction of nmc_compact.hpp; without one
+// its points are simply priced one after the other (fixed order per point: bit-identical under any sharding).
+// lead = path_offset mod kPool: slots of the shard's first group that belong to the previous shard.
+template <typename T>
+__device__ __forceinline__ uint32_t group_lead(const NmcArgs<T> &a)
+{
+    return static_cast<uint32_t>(a.path_offset % kPool);
+}
+template <typename T>
+__device__ __forceinline__ uint64_t groups_per_step_of(const NmcArgs<T> &a)
+{
+    return (group_lead(a) + a.n_local + kPool - 1) / kPool;
+}
 template <typename T, int LAYOUT>
 __device__ __forceinline__ uint64_t stored_index(const NmcArgs<T> &a, uint32_t step, uint64_t path)
 {
     return LAYOUT == MCAMD_STEP_MAJOR ? static_cast<uint64_t>(step) * a.n_local + path : path * a.n_steps + step;
 }
 
-// Prices the points (step, path0 .. path0 + n_pts - 1) with one wavefront and adds them to the wavefront's record
-// (lane 0): rec = {sum of point prices, sum of squares, wave-steps executed, lane-steps of paths with an open window}.
+// Prices the points (step, path0 + s), s = 0 .. kPool - 1, that lie inside the shard (0 <= path0 + s < n_local; path0 is
+// the LOCAL index of the group's slot 0 and is negative in a shard's partial first group) with one wavefront and adds
+// them to the wavefront's record (lane 0): rec = {sum of point prices, sum of squares, wave-steps executed, lane-steps
+// of paths with an open window}.
 template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE>
 __device__ __forceinline__ void price_group(const NmcArgs<T> &a, const StepConsts<T> &c, const MathCtx<T> &m,
                                             const PhiloxKeys &key, const T *prices, const int32_t *counts, uint32_t step,
-                                            uint64_t path0, uint32_t n_pts, ParkedPaths<T, WINDOW> &parked,
-                                            double (&rec)[kNmcRecord])
+                                            int64_t path0, ParkedPaths<T, WINDOW> &parked, double (&rec)[kNmcRecord])
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t remaining = a.n_steps - (step + 1);
+    // slot s of the group holds a point of this shard
+    auto in_shard = [&](uint32_t s) {
+        const int64_t p = path0 + static_cast<int64_t>(s);
+        return p >= 0 && p < static_cast<int64_t>(a.n_local);
+    };
     if constexpr (WINDOW) {
         if (lane < kPool) {   // lane s describes point s of the group
-            const bool present = lane < n_pts;
-            const uint64_t idx = stored_index<T, LAYOUT>(a, step, path0 + (present ? lane : 0u));
+            const bool present = in_shard(lane);
+            const uint64_t idx = stored_index<T, LAYOUT>(a, step, present ? static_cast<uint64_t>(path0 + lane) : 0u);
             const T St0 = prices[idx];
             int32_t cnt0 = counts[idx];
             // a point whose count is already beyond P2 can never pay (inc/nmc.cuh:53,330): no path of it is started
@@ -88,7 +111,9 @@ __device__ __forceinline__ void price_group(const NmcArgs<T> &a, const StepConst
             parked.pt_cnt0[lane] = cnt0;
             parked.pt_log_start[lane] =
                 (cnt0 != kNoPath && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
-            parked.pt_subsequence[lane] = ((a.path_offset + path0 + lane) * a.n_steps + step) * a.n_inner;
+            // global point id = global path * n_steps + step (a.path_offset + path0 >= 0: the group's global start)
+            parked.pt_subsequence[lane] =
+                ((a.path_offset + static_cast<uint64_t>(path0 + lane)) * a.n_steps + step) * a.n_inner;
             parked.pt_n[lane] = a.n_inner;
             parked.pt_sum[lane] = 0.0;
             parked.pt_sumsq[lane] = 0.0;
@@ -99,9 +124,9 @@ __device__ __forceinline__ void price_group(const NmcArgs<T> &a, const StepConst
         wave_lds_fence();
 #pragma unroll
         for (uint32_t s = 0; s < kPool; ++s) {
-            if (lane == 0 && s < n_pts) {
+            if (lane == 0 && in_shard(s)) {
                 const double price = parked.pt_sum[s] * a.scale;
-                a.out[stored_index<T, LAYOUT>(a, step, path0 + s)] = static_cast<T>(price);
+                a.out[stored_index<T, LAYOUT>(a, step, static_cast<uint64_t>(path0 + s))] = static_cast<T>(price);
                 rec[0] += price;
                 rec[1] = __builtin_fma(price, price, rec[1]);
             }
@@ -112,10 +137,12 @@ __device__ __forceinline__ void price_group(const NmcArgs<T> &a, const StepConst
         }
         wave_lds_fence();   // the next group's description must not overtake this group's last reads
     } else {
-        for (uint32_t s = 0; s < n_pts; ++s) {
-            const uint64_t idx = stored_index<T, LAYOUT>(a, step, path0 + s);
+        for (uint32_t s = 0; s < kPool; ++s) {
+            if (!in_shard(s)) continue;   // wave-uniform
+            const uint64_t local = static_cast<uint64_t>(path0 + s);
+            const uint64_t idx = stored_index<T, LAYOUT>(a, step, local);
             const T St0 = prices[idx];
-            const uint64_t point_id = (a.path_offset + path0 + s) * a.n_steps + step;
+            const uint64_t point_id = (a.path_offset + local) * a.n_steps + step;
             double acc = 0.0;
             uint64_t steps_run = 0;   // 64-bit: n_inner / 64 passes of up to 2^32 steps each
             for (uint32_t j = lane; j < a.n_inner; j += kWave)
@@ -144,8 +171,9 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
     const int lane = threadIdx.x & (kWave - 1);
     __shared__ ParkedPaths<T, WINDOW> s_parked[kBlock / kWave];   // one buffer per wavefront (nmc_compact.hpp)
     double rec[kNmcRecord] = {0.0, 0.0, 0.0, 0.0};
-    const uint64_t groups_per_step = (a.n_local + kPool - 1) / kPool;
+    const uint64_t groups_per_step = groups_per_step_of(a);
     const uint64_t n_groups = groups_per_step * a.n_steps;   // step-major: the long tasks come first
+    const int64_t lead = group_lead(a);
     for (;;) {
         unsigned long long first = 0;
         if (lane == 0) first = atomicAdd(queue, 1ull);
@@ -153,9 +181,8 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
                            __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(first));
         if (g >= n_groups) break;
         const uint32_t step = static_cast<uint32_t>(g / groups_per_step);
-        const uint64_t path0 = (g - static_cast<uint64_t>(step) * groups_per_step) * kPool;
-        const uint32_t n_pts = a.n_local - path0 < kPool ? static_cast<uint32_t>(a.n_local - path0) : kPool;
-        price_group<T, WINDOW, LAYOUT, LOGSPACE>(a, c, m, key, a.prices, a.counts, step, path0, n_pts,
+        const int64_t path0 = static_cast<int64_t>((g - static_cast<uint64_t>(step) * groups_per_step) * kPool) - lead;
+        price_group<T, WINDOW, LAYOUT, LOGSPACE>(a, c, m, key, a.prices, a.counts, step, path0,
                                                  s_parked[threadIdx.x / kWave], rec);
     }
     block_sumN<kBlock, kNmcRecord>(rec);
@@ -234,15 +261,17 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
     const int wave = threadIdx.x / kWave;
     const StepConsts<T> c = resident(a.c);
     // owned path groups (kPool adjacent paths each, the groups of nmc_wave_kernel): blockIdx.x, blockIdx.x + G, ...
-    const uint64_t groups_per_step = (a.n_local + kPool - 1) / kPool;
+    const uint64_t groups_per_step = groups_per_step_of(a);
+    const int64_t lead = group_lead(a);
     const uint64_t n_owned = groups_per_step > blockIdx.x ? (groups_per_step - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
 
     // ---- phase 1: outer trajectories of the owned paths (inc/nmc.cuh:144-202) ----
     {
     const PhiloxKeys outer_key = PhiloxKeys::make(outer_seed);   // its 20 registers are free again after this phase
     for (uint64_t i = threadIdx.x; i < n_owned * kPool; i += kBlock) {
-        const uint64_t path = (blockIdx.x + (i / kPool) * gridDim.x) * kPool + i % kPool;
-        if (path >= a.n_local) continue;   // the last group of the row may be short
+        const int64_t lpath = static_cast<int64_t>((blockIdx.x + (i / kPool) * gridDim.x) * kPool + i % kPool) - lead;
+        if (lpath < 0 || lpath >= static_cast<int64_t>(a.n_local)) continue;   // the shard's edge groups may be partial
+        const uint64_t path = static_cast<uint64_t>(lpath);
         PathState<T> ps = PathState<T>::start(c.S_start);
         int32_t cnt = c.Ik;
         Exponents<T> ex;
@@ -277,9 +306,9 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
         const uint64_t task = __builtin_amdgcn_readfirstlane(mine);
         if (task >= n_tasks) break;
         const uint32_t step = static_cast<uint32_t>(task / n_owned);
-        const uint64_t path0 = (blockIdx.x + (task - static_cast<uint64_t>(step) * n_owned) * gridDim.x) * kPool;
-        const uint32_t n_pts = a.n_local - path0 < kPool ? static_cast<uint32_t>(a.n_local - path0) : kPool;
-        price_group<T, WINDOW, LAYOUT, LOGSPACE>(a, c, m, key, prices, counts, step, path0, n_pts, s_parked[wave], rec);
+        const int64_t path0 =
+            static_cast<int64_t>((blockIdx.x + (task - static_cast<uint64_t>(step) * n_owned) * gridDim.x) * kPool) - lead;
+        price_group<T, WINDOW, LAYOUT, LOGSPACE>(a, c, m, key, prices, counts, step, path0, s_parked[wave], rec);
     }
     block_sumN<kBlock, kNmcRecord>(rec);
     if (threadIdx.x == 0) {
@@ -292,7 +321,7 @@ uint32_t nmc_fused_grid(const NmcJob &job)
 {
     // a workgroup owns whole groups of kPool outer paths; many small workgroups (one group each at BASELINE
     // configs[3]) keep the end of the launch short, since a workgroup's work depends on when ITS paths' windows close
-    const uint64_t groups = (job.path.n_local + kPool - 1) / kPool;
+    const uint64_t groups = (job.path.path_offset % kPool + job.path.n_local + kPool - 1) / kPool;
     const uint64_t want = groups < 32768 ? groups : 32768;
     return static_cast<uint32_t>(want < 1 ? 1 : want);
 }
@@ -314,7 +343,7 @@ uint32_t nmc_grid(const NmcJob &job, int variant)
 {
     if (variant == MCAMD_NMC_BLOCK_PER_POINT) return clamp_grid(job.n_points);
     // wave per point: persistent grid, 8 workgroups per CU (all that can be resident), tasks pulled from a queue
-    const uint64_t groups = (job.path.n_local + kPool - 1) / kPool * job.path.n_steps;   // the kernel's tasks
+    const uint64_t groups = (job.path.path_offset % kPool + job.path.n_local + kPool - 1) / kPool * job.path.n_steps;   // the kernel's tasks
     const uint64_t per_block = static_cast<uint64_t>(kBlock / kWave);
     const uint64_t need = (groups + per_block - 1) / per_block;
     const uint64_t resident = static_cast<uint64_t>(job.compute_units ? job.compute_units : 256) * 8;

@@ -36,6 +36,20 @@ def allreduce_stats(sum_: float, sumsq: float, n: int, device="cpu") -> Tuple[fl
     return float(s), float(s2), int(round(nn))
 
 
+def allreduce_vector(values, device="cpu"):
+    """One SUM all-reduce of a short list of doubles (the statistics record plus whatever diagnostics ride along:
+    the nested-MC work counters).  No-op without an initialised process group."""
+    import torch
+    import torch.distributed as dist
+
+    vals = [float(v) for v in values]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return vals
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()
+
+
 def price_sharded(local_stats: Callable[[int, int], Tuple[float, float]], n_total: int, world: int, rank: int,
                   finalize: Callable[[float, float, int], object], device="cpu"):
     """Prices one job across `world` ranks.

@@ -100,3 +100,39 @@ def test_bench_emits_one_json_line_with_roofline_and_cpu_baseline():
     assert dev["arch"].startswith("gfx950") and dev["compute_units"] >= 200 and dev["hbm_free_gb"] > 100
     assert rl["valu_slots_per_path_step"] and "stale" not in rl     # the slot count describes the loaded library
     assert d["cfg1"]["closed_form"]["evals"] == 1_000_000 and d["cfg1"]["serial_mc_port_f64"]["paths"] == 1_000_000
+
+
+def _bench_line(argv, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
+                         timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,strategy", [("nmc", "wave"), ("nmc", "fused"), ("nmc", "block"), ("store", None)])
+def test_two_ranks_sharing_the_card_reproduce_the_one_rank_job(workload, strategy):
+    """the store shards by path columns and nested MC by outer path.  `bench.py --gpus 2 --backend gloo` runs
+    the real kernels as two ranks on this box's one GPU: rank g works on global paths [g n, (g + 1) n) (path_offset != 0
+    on rank 1) and the statistics records are summed over the ranks.  The same global job on ONE rank must give the same
+    reduced result — the mean of all point prices (nested MC) or the price (store)."""
+    per_rank = 64 if workload == "nmc" else 50_000
+    common = ["--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    if strategy:
+        common += ["--nmc-strategy", strategy]
+    two = _bench_line(["--gpus", "2", "--backend", "gloo", "--paths", str(per_rank), *common])
+    one = _bench_line(["--gpus", "1", "--paths", str(2 * per_rank), *common])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["global_paths"] == one["config"]["global_paths"] == 2 * per_rank
+    if workload == "nmc":
+        assert one["mean_point_price"] > 0
+        assert abs(two["mean_point_price"] - one["mean_point_price"]) <= 1e-12 * one["mean_point_price"]
+        # the work counters are the whole job's on both lines: same pools (64 is a multiple of 8), same schedule
+        assert two["executed_inner_path_steps_per_pass"] == one["executed_inner_path_steps_per_pass"]
+        assert two["live_inner_path_steps_per_pass"] == one["live_inner_path_steps_per_pass"]
+    else:
+        assert abs(two["price"] - one["price"]) <= 1e-12 * one["price"]
+        assert abs(two["std_err"] - one["std_err"]) <= 1e-9 * one["std_err"]

@@ -29,7 +29,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mcamd_abi_version() == 4
+    assert lib.mcamd_abi_version() == 5
 
 
 def test_slot_counts_describe_the_built_library(lib):

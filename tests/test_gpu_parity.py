@@ -268,6 +268,90 @@ def test_group_single_process_rccl_route(ctx):
         assert math.isclose(again.sum, ctx.price_paths(opt, capi.make_sim(1_000_003, 12, capi.F64, seed=21)).sum, rel_tol=1e-12)
 
 
+def test_group_store_and_nested_mc_shards(ctx):
+    # mcamd_group_simulate_trajectories / _nmc_inner / _nmc_fused ("trajectory-store mode shards the
+    # [step][path] buffer by path columns per GPU", "NMC shards by outer path; per-point prices stay on the owning GPU"):
+    # per-device caller-owned buffers, every device enqueues its shard, one ncclAllReduce of the statistics record.  One
+    # device on this box, so the clique has one rank and its shard is the whole job: buffers and statistics must equal
+    # the single-context calls exactly.
+    n, n_steps, n_inner = 77, 9, 130
+    opt = capi.make_option(**BENCH, B=104.0, P1=1, P2=5, use_window=1)
+    with capi.Group(1) as g:
+        assert g.size() == 1
+        for prec in (capi.F64, capi.F32):
+            t = TORCH_T[prec]
+            for lo, m in ((0, n), (13, 40)):
+                outer = capi.make_sim(n, n_steps, prec, seed=1234, path_offset=lo, n_paths_local=m)
+                inner = capi.make_sim(n, n_steps, prec, seed=1235, path_offset=lo, n_paths_local=m, n_paths_inner=n_inner)
+                assert g.shard(outer, 0) == (lo, m)
+                T1, C1, P1 = dev(m * n_steps, t), dev(m * n_steps, torch.int32), dev(m, t)
+                T2, C2, P2 = dev(m * n_steps, t), dev(m * n_steps, torch.int32), dev(m, t)
+                want = ctx.simulate_trajectories(opt, outer, T1, C1, P1)
+                got = g.simulate_trajectories(opt, outer, [T2], [C2], [P2])
+                assert torch.equal(T1, T2) and torch.equal(C1, C2) and torch.equal(P1, P2)
+                assert got.n == want.n == m and got.sum == want.sum and got.sumsq == want.sumsq
+                assert got.price == want.price and got.std_err == want.std_err and got.kernel_ms > 0
+                for variant in (capi.NMC_WAVE_PER_POINT, capi.NMC_BLOCK_PER_POINT):
+                    O1, O2 = dev(m * n_steps, t), dev(m * n_steps, t)
+                    wi = ctx.nmc_inner(opt, inner, T1, C1, O1, capi.STEP_MAJOR, variant)
+                    gi = g.nmc_inner(opt, inner, [T2], [C2], [O2], capi.STEP_MAJOR, variant)
+                    assert torch.equal(O1, O2) and gi.n == wi.n == m * n_steps
+                    # the diagnostic mean's summation order follows the task queue (wave kernel): equal to rounding
+                    assert math.isclose(gi.sum, wi.sum, rel_tol=1e-12) and math.isclose(gi.price, wi.price, rel_tol=1e-12)
+                    assert gi.work_steps == wi.work_steps and gi.live_steps == wi.live_steps
+                T3, C3, O3, O1 = dev(m * n_steps, t), dev(m * n_steps, torch.int32), dev(m * n_steps, t), dev(m * n_steps, t)
+                ctx.nmc_inner(opt, inner, T1, C1, O1)
+                gf = g.nmc_fused(opt, inner, 1234, [T3], [C3], [O3])
+                assert torch.equal(T3, T1) and torch.equal(C3, C1) and torch.equal(O3, O1) and gf.n == m * n_steps
+        # empty job, and an error from the enqueue leaves the group usable
+        e = g.simulate_trajectories(opt, capi.make_sim(10, 3, capi.F64, n_paths_local=0), None)
+        assert e.n == 0 and e.sum == 0
+        with pytest.raises(capi.McamdError, match="d_counts"):
+            g.nmc_inner(opt, capi.make_sim(8, 4, capi.F64, n_paths_inner=5), [dev(32, torch.float64)], None,
+                        [dev(32, torch.float64)])
+        again = g.simulate_trajectories(opt, capi.make_sim(8, 4, capi.F64), [dev(32, torch.float64)])
+        assert again.n == 8
+
+
+def test_store_and_nmc_enqueue_forms_match_the_synchronous_calls(ctx):
+    # asynchronous forms: kernels + final reduce enqueued, 6-double statistics record left in device memory
+    n, n_steps, n_inner = 1000, 11, 70
+    opt = capi.make_option(**BENCH, B=104.0, P1=1, P2=5, use_window=1)
+    stats = torch.full((5, 8), -1.0, dtype=torch.float64, device="cuda")
+    for prec in (capi.F64, capi.F32):
+        t = TORCH_T[prec]
+        outer = capi.make_sim(n + 5, n_steps, prec, seed=77, path_offset=3, n_paths_local=n)
+        inner = capi.make_sim(n + 5, n_steps, prec, seed=78, path_offset=3, n_paths_local=n, n_paths_inner=n_inner)
+        T1, C1, P1, O1 = dev(n * n_steps, t), dev(n * n_steps, torch.int32), dev(n, t), dev(n * n_steps, t)
+        T2, C2, P2, O2, O3 = dev(n * n_steps, t), dev(n * n_steps, torch.int32), dev(n, t), dev(n * n_steps, t), dev(n * n_steps, t)
+        T4, C4, O4 = dev(n * n_steps, t), dev(n * n_steps, torch.int32), dev(n * n_steps, t)
+        ctx.simulate_trajectories_enqueue(opt, outer, T2, C2, P2, stats[0])
+        ctx.nmc_inner_enqueue(opt, inner, T2, C2, O2, stats[1])                # ordered after the store on the stream
+        ctx.nmc_inner_enqueue(opt, inner, T2, C2, O3, stats[2], variant=capi.NMC_BLOCK_PER_POINT)
+        ctx.nmc_fused_enqueue(opt, inner, 77, T4, C4, O4, stats[3])
+        ctx.simulate_trajectories_enqueue(opt, capi.make_sim(9, 3, prec, n_paths_local=0), None, None, None, stats[4])
+        ms = ctx.enqueued_kernel_ms(5)
+        assert all(m >= 0 for m in ms) and ms[1] > 0
+        ws = ctx.simulate_trajectories(opt, outer, T1, C1, P1)
+        wi = ctx.nmc_inner(opt, inner, T1, C1, O1)
+        assert torch.equal(T1, T2) and torch.equal(C1, C2) and torch.equal(P1, P2) and torch.equal(O1, O2)
+        assert torch.equal(T4, T1) and torch.equal(C4, C1) and torch.equal(O4, O1)
+        assert torch.allclose(O3, O1, rtol=1e-12 if prec == capi.F64 else 1e-5, atol=1e-12 if prec == capi.F64 else 1e-5)
+        st = stats.tolist()
+        fs = capi.finalize_stats(st[0][:6], opt.r, opt.T)
+        assert st[0][0] == ws.sum and st[0][1] == ws.sumsq and st[0][5] == n and fs.price == ws.price
+        fi = capi.finalize_nmc_stats(st[1][:6])
+        assert fi.n == n * n_steps and math.isclose(fi.sum, wi.sum, rel_tol=1e-12) and fi.work_steps == wi.work_steps
+        assert fi.live_steps == wi.live_steps and math.isclose(fi.price, wi.price, rel_tol=1e-12)
+        assert capi.finalize_nmc_stats(st[3][:6]).n == n * n_steps and st[4][:6] == [0.0] * 6
+    with pytest.raises(capi.McamdError):
+        ctx.simulate_trajectories_enqueue(opt, capi.make_sim(8, 4, capi.F64), dev(32, torch.float64), None, None, None)
+    # the largest inner Philox subsequence of a shard must fit 64 bits
+    with pytest.raises(capi.McamdError, match="subsequence"):
+        ctx.nmc_inner(opt, capi.make_sim(1 << 62, 252, capi.F64, path_offset=(1 << 62) - 8, n_paths_local=8, n_paths_inner=1000),
+                      dev(8 * 252, torch.float64), dev(8 * 252, torch.int32), dev(8 * 252, torch.float64))
+
+
 def test_price_paths_empty_shard_and_errors(ctx):
     res = ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(100, 3, capi.F64, n_paths_local=0))
     assert res.sum == 0 and res.n == 0
@@ -581,6 +665,96 @@ def test_nmc_fused_equals_two_launch_route(ctx, prec, layout, n_paths):
     assert torch.equal(traj, traj2) and torch.equal(cnt, cnt2)
     assert torch.equal(out, out2)
     assert math.isclose(ra.sum, rb.sum, rel_tol=1e-12, abs_tol=1e-12) and rb.n == n_paths * n_steps
+
+
+def _nmc_routes(ctx, opt, prec, layout, n_total, n_steps, n_inner, lo, m, seeds=(1234, 1235)):
+    """Outer store + the three nested-MC strategies on the shard [lo, lo + m) of an n_total-path job.  Returns the stored
+    prices / counts and the point prices of each strategy as (n_steps, m) arrays, plus the results."""
+    t = TORCH_T[prec]
+    outer = capi.make_sim(n_total, n_steps, prec, seed=seeds[0], path_offset=lo, n_paths_local=m)
+    inner = capi.make_sim(n_total, n_steps, prec, seed=seeds[1], path_offset=lo, n_paths_local=m, n_paths_inner=n_inner)
+    traj, cnt = dev(m * n_steps, t), dev(m * n_steps, torch.int32)
+    cnt.zero_()
+    ctx.simulate_trajectories(opt, outer, traj, cnt if opt.use_window else None, None, layout)
+    outs, ress = {}, {}
+    for name, variant in (("wave", capi.NMC_WAVE_PER_POINT), ("block", capi.NMC_BLOCK_PER_POINT)):
+        o_ = dev(m * n_steps, t)
+        ress[name] = ctx.nmc_inner(opt, inner, traj, cnt if opt.use_window else None, o_, layout, variant)
+        outs[name] = o_
+    t2, c2, o2 = dev(m * n_steps, t), dev(m * n_steps, torch.int32), dev(m * n_steps, t)
+    c2.zero_()
+    ress["fused"] = ctx.nmc_fused(opt, inner, seeds[0], t2, c2 if opt.use_window else None, o2, layout)
+    outs["fused"] = o2
+    assert torch.equal(t2, traj) and torch.equal(c2, cnt)     # the fused kernel's outer stage == the store kernel
+    grid = (lambda a: a.view(n_steps, m)) if layout == capi.STEP_MAJOR else (lambda a: a.view(m, n_steps).T)
+    return grid(traj), grid(cnt), {k: grid(v) for k, v in outs.items()}, ress
+
+
+@pytest.mark.parametrize("prec", [capi.F32, capi.F64])
+@pytest.mark.parametrize("layout", [capi.STEP_MAJOR, capi.PATH_MAJOR])
+@pytest.mark.parametrize("window", [1, 0])
+def test_nmc_sharded_equals_whole_job(ctx, prec, layout, window):
+    # SURVEY 8e: "NMC shards by outer path".  A shard [lo, lo + m) of the job — what rank g of a multi-GPU run prices,
+    # path_offset != 0 — must reproduce the whole job's columns: stored trajectories and counts bit for bit, per-point
+    # prices bit for bit wherever the compaction pool is the same set of points as in the whole job (pools are cut at
+    # multiples of 8 of the GLOBAL path id, csrc/nmc.hip), and to fp64 summation order in a shard's partial edge pools.
+    n, n_steps, n_inner = 61, 9, 150
+    opt = (capi.make_option(**BENCH, B=104.0, P1=1, P2=5, use_window=1) if window
+           else capi.make_option(**BENCH))
+    T0, C0, W0, R0 = _nmc_routes(ctx, opt, prec, layout, n, n_steps, n_inner, 0, n)
+    assert torch.equal(W0["wave"], W0["fused"])
+    pool = 8
+    shards = [(0, 16), (16, 24), (3, 13), (40, 21), (7, 1), (33, 28), (1, 60)]   # aligned, odd lo, ragged m, to the end
+    total = {k: 0.0 for k in W0}
+    for lo, m in shards:
+        T1, C1, W1, R1 = _nmc_routes(ctx, opt, prec, layout, n, n_steps, n_inner, lo, m)
+        assert torch.equal(T1, T0[:, lo:lo + m]) and torch.equal(C1, C0[:, lo:lo + m]), (lo, m)
+        assert torch.equal(W1["wave"], W1["fused"]), (lo, m)
+        # block-per-point (no compaction) and the window-less loop sum each point in a fixed order: exact everywhere
+        assert torch.equal(W1["block"], W0["block"][:, lo:lo + m]), (lo, m)
+        same_pool = torch.tensor([max(g * pool, lo) == max(g * pool, 0) and min(g * pool + pool, lo + m) == min(g * pool + pool, n)
+                                  for g in ((lo + q) // pool for q in range(m))], device="cuda")
+        assert same_pool.any() or m < pool
+        want = W0["wave"][:, lo:lo + m]
+        if not window:
+            assert torch.equal(W1["wave"], want), (lo, m)
+        else:
+            assert torch.equal(W1["wave"][:, same_pool], want[:, same_pool]), (lo, m)
+            rtol = 1e-13 if prec == capi.F64 else 2e-6
+            assert torch.allclose(W1["wave"], want, rtol=rtol, atol=rtol), (lo, m)
+        for k in W1:
+            assert R1[k].n == m * n_steps
+            assert math.isclose(R1[k].sum, float(W1[k].double().sum()), rel_tol=1e-6, abs_tol=1e-9)
+
+
+@pytest.mark.parametrize("prec", [capi.F32, capi.F64])
+def test_nmc_shard_deep_in_the_id_space_vs_oracle(ctx, oracle, prec):
+    # a shard whose global path ids lie beyond 2^32 (odd offset, ragged size): every strategy against the oracle's
+    # brute-force point pricer with the SHIFTED point id (global path * n_steps + step), which is what feeds the
+    # inner Philox subsequence (csrc/nmc.hip price_group / nmc_block_kernel)
+    n_total, n_steps, n_inner = 1 << 40, 7, 120
+    lo, m = (1 << 33) + 12_345, 11
+    opt = capi.make_option(**BENCH, B=104.0, P1=1, P2=5, use_window=1)
+    T1, C1, W1, _ = _nmc_routes(ctx, opt, prec, capi.STEP_MAJOR, n_total, n_steps, n_inner, lo, m)
+    # the stored outer rows are the oracle's paths lo .. lo + m - 1
+    po = oracle.make_params(**BENCH, B=104.0, P1=1, P2=5, use_window=1, n_paths=n_total, n_steps=n_steps, seed=1234)
+    ref = oracle.mc_paths(po, prec, lo, m, want_traj=True, want_counts=True)
+    if prec == capi.F64:   # fp32 counts may differ where St is within rounding of the barrier (test_store_vs_oracle)
+        assert np.array_equal(C1.cpu().numpy(), ref["counts"])
+    assert np.allclose(T1.cpu().numpy(), ref["traj"], rtol=1e-12 if prec == capi.F64 else 1e-5)
+    pi = oracle.make_params(**BENCH, B=104.0, P1=1, P2=5, use_window=1, n_paths=n_total, n_steps=n_steps,
+                            n_paths_inner=n_inner, seed=1235)
+    Tn, Cn = T1.cpu().numpy(), C1.cpu().numpy()
+    want = np.array([[oracle.nmc_point(pi, prec, (lo + q) * n_steps + s_, s_, float(Tn[s_, q]), int(Cn[s_, q]))
+                      for q in range(m)] for s_ in range(n_steps)])
+    assert want.max() > 0
+    for k, got in W1.items():
+        assert np.allclose(got.cpu().numpy(), want, rtol=1e-11 if prec == capi.F64 else 5e-3,
+                           atol=1e-9 if prec == capi.F64 else 2e-3), k
+    # and a neighbouring id is a different stream: the offset really reaches the generator
+    _, _, W2, _ = _nmc_routes(ctx, opt, prec, capi.STEP_MAJOR, n_total, n_steps, n_inner, lo + 1, m)
+    assert not torch.equal(W2["wave"], W1["wave"])
+    assert torch.equal(W2["block"][:, :m - 1], W1["block"][:, 1:])
 
 
 @pytest.mark.parametrize("n_inner", [1, 63, 64, 65, 257, 1000])

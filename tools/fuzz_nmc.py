@@ -43,8 +43,14 @@ def main():
         v = float(rng.choice([0.05, 0.2, 0.6]))
         opt = capi.make_option(100.0, 1.0, 100.0, 0.1, v, B=B, P1=P1, P2=P2, use_window=1)
         so, si = int(rng.integers(1, 1 << 30)), int(rng.integers(1 << 30, 1 << 31))
-        outer = capi.make_sim(n_paths, n_steps, prec, seed=so)
-        inner = capi.make_sim(n_paths, n_steps, prec, seed=si, n_paths_inner=n_inner, flags=flags)
+        # the job is a SHARD [lo, lo + n_paths) of a larger one (what a rank of a multi-GPU run prices): lo feeds the
+        # outer stream, the inner subsequences and the cut of the compaction pools (multiples of 8 of the global id)
+        r_ = rng.random()
+        lo = 0 if r_ < 0.3 else int(rng.integers(1, 64)) if r_ < 0.7 else int(rng.integers(1, 1 << 40))
+        n_total = lo + n_paths + int(rng.integers(0, 100))
+        outer = capi.make_sim(n_total, n_steps, prec, seed=so, path_offset=lo, n_paths_local=n_paths)
+        inner = capi.make_sim(n_total, n_steps, prec, seed=si, path_offset=lo, n_paths_local=n_paths, n_paths_inner=n_inner,
+                              flags=flags)
         n = n_paths * n_steps
         traj = torch.empty(n, dtype=tt[prec], device="cuda")
         cnt = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -63,7 +69,7 @@ def main():
         ok = ok and abs(rw.live_steps - rb.live_steps) <= 0.25 * max(rb.live_steps, 1.0) + 64 * 4
         if not ok:
             fails.append({"case": n_cases, "prec": prec, "n_paths": n_paths, "n_steps": n_steps, "n_inner": n_inner, "B": B,
-                          "P1": P1, "P2": P2, "flags": flags, "layout": layout, "v": v, "so": so, "si": si, "dev": dev})
+                          "P1": P1, "P2": P2, "flags": flags, "layout": layout, "v": v, "so": so, "si": si, "lo": lo, "dev": dev})
         n_cases += 1
     print(json.dumps({"cases": n_cases, "worst_rel_dev_f64": worst, "failures": fails[:10], "n_failures": len(fails)}))
     ctx.close()

@@ -71,6 +71,11 @@ extern "C" {
                                   known); the call also returns the three cross sums and the finalized price uses the
                                   sample-optimal beta (mcamd_finalize_cv).  New capability. */
 
+#define MCAMD_FLAG_SEPARATE_REDUCE 8 /* diagnostic (mcamd_price_paths[_enqueue]): sum the block records with a separate
+                                  one-workgroup launch even where the simulation kernel would finish the sum itself (jobs
+                                  of up to 8192 workgroups: its last workgroup to arrive does it).  Same summation order,
+                                  same bits; exists so that a test can show exactly that. */
+
 /* reduce variants: names follow the reference's ReductionType (inc/testing.cuh:100-106) */
 #define MCAMD_REDUCE_SEQUENTIAL 3
 #define MCAMD_REDUCE_FIRST_ADD 4

@@ -390,6 +390,29 @@ __global__ __launch_bounds__(kFinalBlock) void final_reduce_kernel(const double 
     }
 }
 
+// grid_finish's sum as a launch of its own (one workgroup of kBlock threads, small_final_sum's order): what a kernel
+// that finishes itself computes in its last workgroup, for the callers that ask for the separate launch.
+template <int N>
+__global__ __launch_bounds__(kBlock) void small_final_kernel(const double *__restrict__ partials, uint32_t n_records,
+                                                             double *__restrict__ out, double n_value)
+{
+    double v[N];
+    small_final_sum<kBlock, N>(partials, n_records, v);
+    if (threadIdx.x == 0) write_final(out, v, N, n_value);
+}
+
+hipError_t launch_small_final(const double *d_partials, uint32_t n_records, int record_doubles, double *d_out,
+                              hipStream_t stream, double n_value)
+{
+    if (record_doubles == 2)
+        hipLaunchKernelGGL(small_final_kernel<2>, dim3(1), dim3(kBlock), 0, stream, d_partials, n_records, d_out, n_value);
+    else if (record_doubles == 5)
+        hipLaunchKernelGGL(small_final_kernel<5>, dim3(1), dim3(kBlock), 0, stream, d_partials, n_records, d_out, n_value);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t launch_final_reduce(const double *d_partials, uint32_t n_records, int record_doubles, double *d_out,
                                hipStream_t stream, double n_value)
 {

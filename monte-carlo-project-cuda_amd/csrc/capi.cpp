@@ -59,6 +59,8 @@ struct mcamd_ctx {
     uint64_t partial_capacity = 0; // in doubles
     double *d_out = nullptr;       // 8 doubles
     unsigned long long *d_queue = nullptr;  // task counter of the wave-per-point nested-MC kernel
+    unsigned int *d_ticket = nullptr;       // arrival counter of kernels that finish their own sum (in d_queue's allocation)
+    double *h_out_dev = nullptr;            // h_out as the device addresses it (a self-finishing kernel writes there)
     uint32_t compute_units = 0;
     double *h_out = nullptr;       // pinned, 8 doubles
     // asynchronous calls: a ring of event pairs around the simulation kernel of the last kRing enqueues
@@ -95,7 +97,7 @@ int check_common(const mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim 
         return fail(MCAMD_ERR_INVALID, "option parameters must be finite with T > 0 and v >= 0");
     if (!(opt->dt >= 0.0) || !std::isfinite(opt->dt))
         return fail(MCAMD_ERR_INVALID, "dt must be 0 (= T / n_steps) or a positive finite step, got %g", opt->dt);
-    if (sim->flags & ~(MCAMD_FLAG_LOG_SPACE | MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE))
+    if (sim->flags & ~(MCAMD_FLAG_LOG_SPACE | MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE | MCAMD_FLAG_SEPARATE_REDUCE))
         return fail(MCAMD_ERR_INVALID, "unknown bits in flags: %d", sim->flags);
     if (sim->path_offset + sim->n_paths_local < sim->path_offset)
         return fail(MCAMD_ERR_INVALID, "path_offset + n_paths_local overflows 64 bits");
@@ -144,17 +146,30 @@ void zero_result(mcamd_result *res)
     std::memset(res, 0, sizeof *res);
 }
 
+// How the block records of the kernel just enqueued reach the host.
+enum class Finish {
+    kFolded,    // the kernel summed them itself and wrote the final record into ctx->h_out (pinned host memory)
+    kSmall,     // separate launch of the same sum (launch_small_final), then a copy
+    kReduce     // separate 1024-thread reduction (launch_final_reduce), then a copy
+};
+
 // final reduce of the block records -> host, with event timing; fills the raw sums + timings
-int finish(mcamd_ctx *ctx, uint32_t records, mcamd_result *res, int record_doubles = 2)
+int finish(mcamd_ctx *ctx, uint32_t records, mcamd_result *res, int record_doubles = 2, Finish how = Finish::kReduce)
 {
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-    HIP_TRY(mcamd::launch_final_reduce(ctx->d_partials, records, record_doubles, ctx->d_out, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, record_doubles * sizeof(double), hipMemcpyDeviceToHost,
-                           ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->ev2, ctx->stream));
+    if (how != Finish::kFolded) {
+        if (how == Finish::kSmall)
+            HIP_TRY(mcamd::launch_small_final(ctx->d_partials, records, record_doubles, ctx->d_out, ctx->stream));
+        else
+            HIP_TRY(mcamd::launch_final_reduce(ctx->d_partials, records, record_doubles, ctx->d_out, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, record_doubles * sizeof(double), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev2, ctx->stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipEventElapsedTime(&res->kernel_ms, ctx->ev0, ctx->ev1));
-    HIP_TRY(hipEventElapsedTime(&res->total_ms, ctx->ev0, ctx->ev2));
+    if (how == Finish::kFolded) res->total_ms = res->kernel_ms;   // one launch is the whole call
+    else HIP_TRY(hipEventElapsedTime(&res->total_ms, ctx->ev0, ctx->ev2));
     res->sum = ctx->h_out[0];
     res->sumsq = ctx->h_out[1];
     if (record_doubles == 5) {
@@ -175,9 +190,9 @@ void finalize_into(double sum, double sumsq, uint64_t n, double r, double T, mca
 // Common tail of the pricing calls: final reduce + copy + sync, then price / SE / CI from the shard's sums,
 // keeping the event timings and the launch shape in the result.
 int finish_pricing(mcamd_ctx *ctx, uint32_t grid, int record_doubles, const mcamd_option *opt, const mcamd_sim *sim,
-                   mcamd_result *res)
+                   mcamd_result *res, Finish how = Finish::kReduce)
 {
-    if (int rc = finish(ctx, grid, res, record_doubles)) return rc;
+    if (int rc = finish(ctx, grid, res, record_doubles, how)) return rc;
     const float kms = res->kernel_ms, tms = res->total_ms;
     if (record_doubles == 5) {
         const double sums[5] = {res->sum, res->sumsq, res->sum_c, res->sum_cc, res->sum_yc};
@@ -320,7 +335,7 @@ int enqueue_empty(mcamd_ctx *ctx, double *d_stats)
 // ctx->d_partials) between a pair of ring events; the final reduce then leaves {record, zeros.., n_value} — the
 // 6-double statistics layout — in d_stats.  Nothing waits on the host.
 template <typename Launch>
-int enqueue_with_stats(mcamd_ctx *ctx, uint32_t grid, int rec, double n_value, double *d_stats, Launch launch)
+int enqueue_with_stats(mcamd_ctx *ctx, uint32_t grid, int rec, double n_value, double *d_stats, Finish how, Launch launch)
 {
     const uint32_t slot = static_cast<uint32_t>(ctx->n_enqueued % mcamd_ctx::kRing);
     // growing the scratch buffer frees the old one: wait for work that may still read it
@@ -329,7 +344,8 @@ int enqueue_with_stats(mcamd_ctx *ctx, uint32_t grid, int rec, double n_value, d
     HIP_TRY(hipEventRecord(ctx->ring0[slot], ctx->stream));
     HIP_TRY(launch());
     HIP_TRY(hipEventRecord(ctx->ring1[slot], ctx->stream));
-    HIP_TRY(mcamd::launch_final_reduce(ctx->d_partials, grid, rec, d_stats, ctx->stream, n_value));
+    if (how == Finish::kSmall) HIP_TRY(mcamd::launch_small_final(ctx->d_partials, grid, rec, d_stats, ctx->stream, n_value));
+    else if (how == Finish::kReduce) HIP_TRY(mcamd::launch_final_reduce(ctx->d_partials, grid, rec, d_stats, ctx->stream, n_value));
     ctx->n_enqueued++;
     return MCAMD_OK;
 }
@@ -407,8 +423,11 @@ int mcamd_ctx_create(int device, void *hip_stream, mcamd_ctx **out)
     }
     if (e == hipSuccess) e = hipMalloc(&ctx->d_out, 8 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_queue, 64);
+    if (e == hipSuccess) e = hipMemset(ctx->d_queue, 0, 64);   // the ticket must be zero at a kernel's first launch
+    if (e == hipSuccess) ctx->d_ticket = reinterpret_cast<unsigned int *>(ctx->d_queue + 2);
     ctx->compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
     if (e == hipSuccess) e = hipHostMalloc(&ctx->h_out, 8 * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_out_dev), ctx->h_out, 0);
     if (e != hipSuccess) {
         mcamd_ctx_destroy(ctx);
         return fail(MCAMD_ERR_HIP, "context setup: %s", hipGetErrorString(e));
@@ -519,9 +538,18 @@ int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *
     const int rec = (job.vr & 2) ? 5 : 2;
     const uint32_t grid = mcamd::price_grid(job, ctx->compute_units);
     if (int rc = ensure_partials(ctx, grid, rec)) return rc;
+    // few records: the kernel's last workgroup sums them and writes the result straight into pinned host memory —
+    // one launch and no copy per call (the reference's shape, inc/trajectories.cuh:77-111 + one cudaMemcpy)
+    const Finish how = grid > mcamd::kFoldMaxRecords ? Finish::kReduce
+                       : (sim->flags & MCAMD_FLAG_SEPARATE_REDUCE) ? Finish::kSmall : Finish::kFolded;
+    mcamd::FinishSpec fs;
+    if (how == Finish::kFolded) {
+        fs.out = ctx->h_out_dev;
+        fs.ticket = ctx->d_ticket;
+    }
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    HIP_TRY(mcamd::launch_price(job, ctx->compute_units, ctx->d_partials, ctx->d_queue, grid, ctx->stream));
-    return finish_pricing(ctx, grid, rec, opt, sim, res);
+    HIP_TRY(mcamd::launch_price(job, ctx->compute_units, ctx->d_partials, ctx->d_queue, grid, fs, ctx->stream));
+    return finish_pricing(ctx, grid, rec, opt, sim, res, how);
 }
 
 int mcamd_price_paths_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, double *d_stats)
@@ -534,8 +562,16 @@ int mcamd_price_paths_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mca
     const mcamd::PathJob job = make_job(opt, sim);
     const int rec = (job.vr & 2) ? 5 : 2;
     const uint32_t grid = mcamd::price_grid(job, ctx->compute_units);
-    return enqueue_with_stats(ctx, grid, rec, static_cast<double>(sim->n_paths_local), d_stats, [&] {
-        return mcamd::launch_price(job, ctx->compute_units, ctx->d_partials, ctx->d_queue, grid, ctx->stream);
+    const Finish how = grid > mcamd::kFoldMaxRecords ? Finish::kReduce
+                       : (sim->flags & MCAMD_FLAG_SEPARATE_REDUCE) ? Finish::kSmall : Finish::kFolded;
+    mcamd::FinishSpec fs;
+    if (how == Finish::kFolded) {   // the kernel leaves the statistics record in d_stats itself
+        fs.out = d_stats;
+        fs.ticket = ctx->d_ticket;
+        fs.n_value = static_cast<double>(sim->n_paths_local);
+    }
+    return enqueue_with_stats(ctx, grid, rec, static_cast<double>(sim->n_paths_local), d_stats, how, [&] {
+        return mcamd::launch_price(job, ctx->compute_units, ctx->d_partials, ctx->d_queue, grid, fs, ctx->stream);
     });
 }
 
@@ -548,7 +584,7 @@ int mcamd_simulate_trajectories_enqueue(mcamd_ctx *ctx, const mcamd_option *opt,
     HIP_TRY(hipSetDevice(ctx->device));
     if (sim->n_paths_local == 0) return enqueue_empty(ctx, d_stats);
     const uint32_t grid = mcamd::store_grid(job.n_local, job.precision);
-    return enqueue_with_stats(ctx, grid, 2, static_cast<double>(sim->n_paths_local), d_stats, [&] {
+    return enqueue_with_stats(ctx, grid, 2, static_cast<double>(sim->n_paths_local), d_stats, Finish::kReduce, [&] {
         return mcamd::launch_store(job, layout, d_traj, d_counts, d_payoffs, ctx->d_partials, grid, ctx->stream);
     });
 }
@@ -562,7 +598,7 @@ int mcamd_nmc_inner_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd
     HIP_TRY(hipSetDevice(ctx->device));
     if (sim->n_paths_local == 0) return enqueue_empty(ctx, d_stats);
     const uint32_t grid = mcamd::nmc_grid(job, variant);
-    return enqueue_with_stats(ctx, grid, mcamd::kNmcRecord, static_cast<double>(job.n_points), d_stats, [&] {
+    return enqueue_with_stats(ctx, grid, mcamd::kNmcRecord, static_cast<double>(job.n_points), d_stats, Finish::kReduce, [&] {
         return mcamd::launch_nmc_inner(job, layout, variant, d_prices, d_counts, d_point_prices, ctx->d_partials,
                                        ctx->d_queue, grid, ctx->stream);
     });
@@ -577,7 +613,7 @@ int mcamd_nmc_fused_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd
     HIP_TRY(hipSetDevice(ctx->device));
     if (sim->n_paths_local == 0) return enqueue_empty(ctx, d_stats);
     const uint32_t grid = mcamd::nmc_fused_grid(job);
-    return enqueue_with_stats(ctx, grid, mcamd::kNmcRecord, static_cast<double>(job.n_points), d_stats, [&] {
+    return enqueue_with_stats(ctx, grid, mcamd::kNmcRecord, static_cast<double>(job.n_points), d_stats, Finish::kReduce, [&] {
         return mcamd::launch_nmc_fused(job, outer_seed, layout, d_prices, d_counts, d_point_prices, ctx->d_partials, grid,
                                        ctx->stream);
     });

@@ -30,8 +30,26 @@ constexpr uint32_t kMaxGrid = 1u << 20;  // blocks; beyond this the kernels grid
 // compute_units: of the device the job runs on (0: 256).  d_queue: one 64-bit word of device memory, used (and zeroed on
 // `stream`) when the job goes to the lane-compacting window kernel, which pulls its tasks from it.
 uint32_t price_grid(const PathJob &job, uint32_t compute_units);
+
+// How a grid's block records become the final record.  ticket != nullptr: the simulation kernel finishes itself — the
+// last workgroup to arrive sums the records in small_final_sum's order and writes out[0..N) (and, with n_value >= 0,
+// the 6-double statistics layout); *ticket must be zero at launch and is zero again afterwards.  ticket == nullptr:
+// the kernel only leaves its records and the caller launches launch_small_final (same order, same bits) or
+// launch_final_reduce (grids of more than kFoldMaxRecords records).
+struct FinishSpec {
+    double *out = nullptr;
+    unsigned int *ticket = nullptr;
+    double n_value = -1.0;
+};
+// One workgroup of 256 threads sums up to this many records in a few microseconds; beyond it the separate
+// 1024-thread reduction is faster than the lone last workgroup.
+constexpr uint32_t kFoldMaxRecords = 8192;
+
 hipError_t launch_price(const PathJob &job, uint32_t compute_units, double *d_partials, unsigned long long *d_queue,
-                        uint32_t grid, hipStream_t stream);
+                        uint32_t grid, const FinishSpec &finish, hipStream_t stream);
+// the separate launch of grid_finish's sum: n_records <= kFoldMaxRecords records of record_doubles (2 or 5) doubles
+hipError_t launch_small_final(const double *d_partials, uint32_t n_records, int record_doubles, double *d_out,
+                              hipStream_t stream, double n_value = -1.0);
 
 uint32_t store_grid(uint64_t n_local, int precision);
 hipError_t launch_store(const PathJob &job, int layout, void *d_traj, int32_t *d_counts, void *d_payoffs,

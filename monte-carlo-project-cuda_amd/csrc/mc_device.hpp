@@ -588,4 +588,102 @@ __device__ __forceinline__ void block_sumN(double (&v)[N])
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Finishing a grid.  The reference finishes inside the simulation kernel with one atomicAdd per block into a float
+// (inc/trajectories.cuh:77-111): one launch, but the result depends on the order the blocks arrive in.  Here a block
+// leaves one record (N doubles) in `partials`, and the records are summed in ONE fixed order (small_final_sum) by a
+// single workgroup — either the last workgroup of the simulation grid to finish (grid_finish: one launch, as the
+// reference) or a separate one-workgroup launch.  Same function, same order, same bits either way.
+// ---------------------------------------------------------------------------------------------
+// Sums n_records records of N doubles with the BLOCK threads of one workgroup in a fixed order: thread t takes records
+// t, t + BLOCK, ... round-robin into kAcc = 4 independent accumulator sets (more would push the pricing kernels past 80 vector registers, i.e. below six wavefronts per SIMD; four loads in flight per lane hide most of the L2
+// latency of the lone workgroup), the sets are added pairwise, block_sumN finishes.  Result valid in thread 0.
+template <int BLOCK, int N>
+__device__ __forceinline__ void small_final_sum(const double *__restrict__ partials, uint32_t n_records, double (&v)[N])
+{
+    constexpr int kAcc = 4;
+    double s[kAcc][N];
+#pragma unroll
+    for (int u = 0; u < kAcc; ++u)
+#pragma unroll
+        for (int k = 0; k < N; ++k) s[u][k] = 0.0;
+    uint32_t i = threadIdx.x;
+    for (; i + (kAcc - 1) * BLOCK < n_records; i += kAcc * BLOCK) {
+#pragma unroll
+        for (int u = 0; u < kAcc; ++u)
+#pragma unroll
+            for (int k = 0; k < N; ++k) s[u][k] += partials[static_cast<uint64_t>(i + u * BLOCK) * N + k];
+    }
+#pragma unroll
+    for (int u = 0; u < kAcc - 1; ++u)   // the last, partial sweep keeps each record in the set the full sweeps give it
+        if (i + u * BLOCK < n_records) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) s[u][k] += partials[static_cast<uint64_t>(i + u * BLOCK) * N + k];
+        }
+#pragma unroll
+    for (int w = 1; w < kAcc; w *= 2)
+#pragma unroll
+        for (int u = 0; u + w < kAcc; u += 2 * w)
+#pragma unroll
+            for (int k = 0; k < N; ++k) s[u][k] += s[u + w][k];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = s[0][k];
+    block_sumN<BLOCK, N>(v);
+}
+
+// Where a grid's final record goes: N doubles to out[0..N); with n_value >= 0 the 6-double statistics layout
+// (out[N..5) = 0, out[5] = n_value) that one all-reduce carries.
+__device__ __forceinline__ void write_final(double *__restrict__ out, const double *v, int n, double n_value)
+{
+    for (int k = 0; k < n; ++k) out[k] = v[k];
+    if (n_value >= 0.0) {
+        for (int k = n; k < 5; ++k) out[k] = 0.0;
+        out[5] = n_value;
+    }
+}
+
+struct GridFinish {
+    double *out;            // final record (device memory, or pinned host memory the device can write)
+    unsigned int *ticket;   // arrival counter, zero at launch (the last workgroup leaves it zero again); nullptr: the
+                            // kernel only writes its block records and a separate launch sums them
+    double n_value;
+};
+
+// Every thread of the workgroup calls this once, after its block sum (v valid in thread 0; contains barriers).
+// Thread 0 publishes the block's record and takes a ticket; the workgroup whose ticket is the last one sums all
+// records.  Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): producer = plain stores by ONE lane, agent-
+// scope release fence, s_waitcnt vmcnt(0) (kept in inline asm: the compiler may drop its own wait after the fence),
+// relaxed agent-scope atomic add; consumer = the lane whose add came last, agent-scope acquire fence, s_waitcnt,
+// workgroup barrier, plain loads.  Per-XCD L2s are not coherent: the release writes the record back, the acquire
+// drops what the reading CU may hold of the array from an earlier launch.
+template <int BLOCK, int N>
+__device__ __forceinline__ void grid_finish(double (&v)[N], double *__restrict__ partials, const GridFinish &f)
+{
+    __shared__ unsigned int s_last;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) partials[static_cast<uint64_t>(N) * blockIdx.x + k] = v[k];
+        unsigned int last = 0;
+        if (f.ticket != nullptr) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int t = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (t == gridDim.x - 1) ? 1u : 0u;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (s_last == 0) return;   // workgroup-uniform
+    double t[N];
+    small_final_sum<BLOCK, N>(partials, gridDim.x, t);
+    if (threadIdx.x == 0) {
+        write_final(f.out, t, N, f.n_value);
+        __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+}
+
 }  // namespace mcamd

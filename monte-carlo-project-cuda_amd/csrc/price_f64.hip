@@ -4,9 +4,9 @@
 
 namespace mcamd {
 
-hipError_t launch_price_f32(const PathJob &j, double *d_partials, uint32_t grid, hipStream_t stream);
+hipError_t launch_price_f32(const PathJob &j, double *d_partials, uint32_t grid, const GridFinish &fin, hipStream_t stream);
 hipError_t launch_price_compact_f32(const PathJob &j, double *d_partials, unsigned long long *d_queue, uint32_t grid,
-                                    hipStream_t stream);
+                                    const GridFinish &fin, hipStream_t stream);
 
 // One path per thread when a path is long (fine-grained blocks keep the tail short); for short paths
 // (few steps) a thread takes several, so that a block still carries a few thousand path-steps and the
@@ -22,13 +22,14 @@ uint32_t price_grid(const PathJob &j, uint32_t compute_units)
 }
 
 hipError_t launch_price(const PathJob &j, uint32_t compute_units, double *d_partials, unsigned long long *d_queue,
-                        uint32_t grid, hipStream_t stream)
+                        uint32_t grid, const FinishSpec &finish, hipStream_t stream)
 {
+    const GridFinish fin{finish.out, finish.ticket, finish.n_value};
     if (price_compacts(j, compute_units))
-        return j.precision == 32 ? launch_price_compact_f32(j, d_partials, d_queue, grid, stream)
-                                 : launch_price_compact_t<double>(j, d_partials, d_queue, grid, stream);
-    return j.precision == 32 ? launch_price_f32(j, d_partials, grid, stream)
-                             : launch_price_t<double>(j, d_partials, grid, stream);
+        return j.precision == 32 ? launch_price_compact_f32(j, d_partials, d_queue, grid, fin, stream)
+                                 : launch_price_compact_t<double>(j, d_partials, d_queue, grid, fin, stream);
+    return j.precision == 32 ? launch_price_f32(j, d_partials, grid, fin, stream)
+                             : launch_price_t<double>(j, d_partials, grid, fin, stream);
 }
 
 }  // namespace mcamd

@@ -9,8 +9,10 @@
 //   - the path is the unit of work, indexed by its 64-bit GLOBAL id, so any shard of any job
 //     draws the same numbers;
 //   - per-thread fp64 sums -> wave64 shuffle -> one LDS slot per wave -> one partial record per
-//     block, finished by a second tiny kernel: deterministic, no float atomics, no reliance on
-//     pre-zeroed memory (SURVEY 2.4-2,7);
+//     block, summed in a fixed order by the LAST workgroup to finish (grid_finish, mc_device.hpp: one
+//     launch, like the reference's in-kernel atomicAdd finish, inc/trajectories.cuh:77-111) or, for
+//     grids with many records, by a second one-workgroup kernel: deterministic, no float atomics, no
+//     reliance on pre-zeroed payoff memory (SURVEY 2.4-2,7);
 //   - the tail is handled by predicating the work, not the reduction.
 // HBM traffic: one record (16 or 40 bytes) per block.  The kernel is VALU-bound (integer multiplies
 // of Philox, Box-Muller, exp).
@@ -33,6 +35,7 @@ struct PriceArgs {
     uint64_t path_offset;
     uint64_t n_local;
     double control_mean;  // E[S_T] = S_start exp(r T_remaining)
+    GridFinish fin;       // where the grid's final record goes when the kernel finishes the sum itself
 };
 
 template <typename T, bool WINDOW, bool LOGSPACE, int VR>
@@ -61,10 +64,7 @@ __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *_
         }
     }
     block_sumN<kBlock, N>(acc);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) partials[static_cast<uint64_t>(N) * blockIdx.x + i] = acc[i];
-    }
+    grid_finish<kBlock, N>(acc, partials, a.fin);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -121,10 +121,7 @@ __global__ __launch_bounds__(kBlock) void price_window_compact_kernel(PriceArgs<
         wave_lds_fence();   // the next group's description must not overtake these reads
     }
     block_sumN<kBlock, 2>(acc);
-    if (threadIdx.x == 0) {
-        partials[2 * static_cast<uint64_t>(blockIdx.x)] = acc[0];
-        partials[2 * static_cast<uint64_t>(blockIdx.x) + 1] = acc[1];
-    }
+    grid_finish<kBlock, 2>(acc, partials, a.fin);
 }
 
 // Compaction pays once every SIMD can be kept busy with whole groups; below that the one-path-per-thread kernel's
@@ -138,9 +135,9 @@ inline bool price_compacts(const PathJob &j, uint32_t compute_units)
 
 template <typename T>
 static hipError_t launch_price_compact_t(const PathJob &j, double *d_partials, unsigned long long *d_queue, uint32_t grid,
-                                         hipStream_t stream)
+                                         const GridFinish &fin, hipStream_t stream)
 {
-    const PriceArgs<T> a{make_consts<T>(j), j.seed, j.path_offset, j.n_local, j.control_mean};
+    const PriceArgs<T> a{make_consts<T>(j), j.seed, j.path_offset, j.n_local, j.control_mean, fin};
     const hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
     const dim3 g(grid), b(kBlock);
@@ -162,9 +159,10 @@ static void launch_price_vr(const PriceArgs<T> &a, int vr, double *d_partials, u
 }
 
 template <typename T>
-static hipError_t launch_price_t(const PathJob &j, double *d_partials, uint32_t grid, hipStream_t stream)
+static hipError_t launch_price_t(const PathJob &j, double *d_partials, uint32_t grid, const GridFinish &fin,
+                                 hipStream_t stream)
 {
-    const PriceArgs<T> a{make_consts<T>(j), j.seed, j.path_offset, j.n_local, j.control_mean};
+    const PriceArgs<T> a{make_consts<T>(j), j.seed, j.path_offset, j.n_local, j.control_mean, fin};
     if (j.window) {
         if (j.logspace) launch_price_vr<T, true, true>(a, j.vr, d_partials, grid, stream);
         else launch_price_vr<T, true, false>(a, j.vr, d_partials, grid, stream);

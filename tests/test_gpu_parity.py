@@ -243,6 +243,64 @@ def test_price_paths_enqueue_matches_synchronous_call(ctx):
         ctx.price_paths_enqueue(opt, sims[0], None)
 
 
+def test_in_kernel_finish_equals_the_separate_reduction_bit_for_bit(ctx):
+    # Jobs of up to 8192 workgroups finish inside the simulation kernel: the last workgroup to arrive sums the block
+    # records (one launch, like the reference's in-kernel finish inc/trajectories.cuh:77-111, but in a FIXED order).
+    # MCAMD_FLAG_SEPARATE_REDUCE runs the same sum as a launch of its own: every statistic must be the same bits, for
+    # every record shape (2 / 5 doubles), both precisions, the window kernels and the lane-compacting kernel, in the
+    # synchronous and the enqueue form.  Repeated with other work in flight on the device: the hand-off between
+    # workgroups (release / ticket / acquire) must hold when the arrivals are spread out, not only on an idle chip.
+    plain, bullet = capi.make_option(**BENCH), capi.make_option(**BENCH, B=120.0, P1=10, P2=50, use_window=1)
+    vr = capi.FLAG_ANTITHETIC | capi.FLAG_CONTROL_VARIATE
+    jobs = [(plain, 1, 1, capi.F64, 0), (plain, 255, 3, capi.F32, 0), (plain, 256, 7, capi.F64, 0),
+            (plain, 100_003, 30, capi.F64, 0), (plain, 1_000_000, 20, capi.F32, 0), (plain, 2_097_152, 8, capi.F64, 0),
+            (plain, 300_000, 16, capi.F64, vr), (plain, 77_777, 9, capi.F32, capi.FLAG_CONTROL_VARIATE),
+            (bullet, 200_001, 60, capi.F64, 0), (bullet, 4_000_000, 64, capi.F32, 0),
+            (plain, 50_000, 40, capi.F64, capi.FLAG_LOG_SPACE)]
+    noise_stream = torch.cuda.Stream()
+    x = torch.randn(1 << 26, device="cuda")
+    stats = torch.zeros(2, 8, dtype=torch.float64, device="cuda")
+    for rep in range(3):
+        for opt, n, steps, prec, flags in jobs:
+            sim = capi.make_sim(n, steps, prec, seed=500 + rep, flags=flags)
+            sep = capi.make_sim(n, steps, prec, seed=500 + rep, flags=flags | capi.FLAG_SEPARATE_REDUCE)
+            with torch.cuda.stream(noise_stream):   # unrelated memory traffic beside the kernels
+                x.mul_(1.0000001)
+            a, b = ctx.price_paths(opt, sim), ctx.price_paths(opt, sep)
+            assert a.grid == b.grid and a.grid <= 8192
+            # the lane-compacting kernel hands its groups out from a queue: which workgroup sums which group follows
+            # the arrival order, so its block records (not only their sum) differ from launch to launch by rounding
+            queued = opt.use_window and n >= 256 * 12 * 1024
+            for k in ("sum", "sumsq", "sum_c", "sum_cc", "sum_yc", "n", "price", "std_err"):
+                if queued:
+                    assert math.isclose(getattr(a, k), getattr(b, k), rel_tol=1e-12), (n, steps, prec, flags, k)
+                else:
+                    assert getattr(a, k) == getattr(b, k), (n, steps, prec, flags, k)
+            assert a.sum > 0 and a.kernel_ms > 0
+            ctx.price_paths_enqueue(opt, sim, stats[0])
+            ctx.price_paths_enqueue(opt, sep, stats[1])
+            torch.cuda.synchronize()
+            assert stats[0, 5].item() == n == stats[1, 5].item()
+            if not queued:
+                assert torch.equal(stats[0, :6], stats[1, :6]) and stats[0, 0].item() == a.sum
+            else:
+                assert torch.allclose(stats[0, :6], stats[1, :6], rtol=1e-12, atol=0)
+    # many small self-finishing launches back to back: the arrival counter is left at zero by each
+    opt = capi.make_option(**BENCH)
+    want = [ctx.price_paths(opt, capi.make_sim(5000 + i, 4, capi.F64, seed=i, flags=capi.FLAG_SEPARATE_REDUCE)).sum
+            for i in range(40)]
+    many = torch.zeros(40, 8, dtype=torch.float64, device="cuda")
+    for i in range(40):
+        ctx.price_paths_enqueue(opt, capi.make_sim(5000 + i, 4, capi.F64, seed=i), many[i])
+    torch.cuda.synchronize()
+    assert many[:, 0].tolist() == want
+    # a grid one workgroup past the limit takes the separate 1024-thread reduction, whatever the flag says
+    big = ctx.price_paths(opt, capi.make_sim(8193 * 256, 32, capi.F32, seed=3))
+    big2 = ctx.price_paths(opt, capi.make_sim(8193 * 256, 32, capi.F32, seed=3, flags=capi.FLAG_SEPARATE_REDUCE))
+    assert big.grid == 8193 and big.sum == big2.sum and big.total_ms >= big.kernel_ms
+    del x
+
+
 def test_group_single_process_rccl_route(ctx):
     # mcamd_group_*: contexts + ncclCommInitAll + one ncclAllReduce of the statistics record.  One device on this
     # box, so the clique has one rank; the shard logic and the RCCL calls are the ones an 8-GPU host runs.
@@ -414,7 +472,7 @@ def test_log_space_restart_and_price(ctx, oracle):
     big = ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(4_000_000, 252, capi.F64, flags=capi.FLAG_LOG_SPACE))
     assert abs(big.price - BS) <= 4 * big.std_err
     with pytest.raises(capi.McamdError):
-        ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(10, 2, capi.F64, flags=8))
+        ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(10, 2, capi.F64, flags=16))
 
 
 def test_log_space_nmc_matches_plain(ctx):

@@ -562,7 +562,7 @@ def main(argv=None):
         elif wl in ("european252", "european252_f32"):
             f64 = prec == capi.F64
             line["roofline"] = valu_roofline(W, stale, "price_f64" if f64 else "price_f32",
-                                             f"price_kernel<{'double' if f64 else 'float'},false>",
+                                             f"price_kernel<{'double' if f64 else 'float'},no window,log-space>",
                                              per_gpu * n_steps / avg_kernel_s,
                                              "price_kernel<double" if f64 else "price_kernel<float")
 
@@ -593,19 +593,19 @@ def main(argv=None):
                 sweep.append(e)
         line["sweep"] = sweep
 
-    # opt-in log-space stepping (MCAMD_FLAG_LOG_SPACE): same draws, ln(St/S0) carried instead of St.  Reported
-    # beside the headline, never as the headline (the headline is the reference's recurrence as written).  Measured
-    # BEFORE the store pass: the clock stays low for a while after 100 GB of stores, which cost this leg 13 % in r02's
-    # first artifacts.
+    # the opt-in product form (MCAMD_FLAG_PRODUCT_FORM): St *= exp(...) every step, the reference's recurrence as written
+    # and the form whose terminal price is the same bits as the store kernel's last row.  Reported beside the headline
+    # (which sums the log-returns and exponentiates once: same draws, same scheme).  Measured BEFORE the store pass: the
+    # clock stays low for a while after 100 GB of stores.
     if solo and wl == "european252":
         ks = []
         for i in range(12):
-            rl = ctx.price_paths(opt, capi.make_sim(n_total, n_steps, prec, 1234 + i, lo, per_gpu, flags=capi.FLAG_LOG_SPACE))
+            rl = ctx.price_paths(opt, capi.make_sim(n_total, n_steps, prec, 1234 + i, lo, per_gpu, flags=capi.FLAG_PRODUCT_FORM))
             ks.append(rl.kernel_ms)
         kms = sum(ks[2:]) / len(ks[2:])
-        line["log_space_mode"] = {"kernel_ms": kms, "paths_per_s_kernel": per_gpu / (kms / 1e3), "price": rl.price,
-                                  "std_err": rl.std_err, "abs_err_vs_bs": abs(rl.price - BS_EXACT),
-                                  "valu_slots_per_path_step": W.get("price_f64_logspace")}
+        line["product_form_mode"] = {"kernel_ms": kms, "paths_per_s_kernel": per_gpu / (kms / 1e3), "price": rl.price,
+                                     "std_err": rl.std_err, "abs_err_vs_bs": abs(rl.price - BS_EXACT),
+                                     "valu_slots_per_path_step": W.get("price_f64_product")}
 
     # bandwidth-bound path, one untimed pass of configs[2] beside the headline (N=1 only)
     if solo and wl == "european252" and not args.no_store_roofline:

@@ -97,8 +97,11 @@ int check_common(const mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim 
         return fail(MCAMD_ERR_INVALID, "option parameters must be finite with T > 0 and v >= 0");
     if (!(opt->dt >= 0.0) || !std::isfinite(opt->dt))
         return fail(MCAMD_ERR_INVALID, "dt must be 0 (= T / n_steps) or a positive finite step, got %g", opt->dt);
-    if (sim->flags & ~(MCAMD_FLAG_LOG_SPACE | MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE | MCAMD_FLAG_SEPARATE_REDUCE))
+    if (sim->flags & ~(MCAMD_FLAG_LOG_SPACE | MCAMD_FLAG_ANTITHETIC | MCAMD_FLAG_CONTROL_VARIATE | MCAMD_FLAG_SEPARATE_REDUCE |
+                       MCAMD_FLAG_PRODUCT_FORM))
         return fail(MCAMD_ERR_INVALID, "unknown bits in flags: %d", sim->flags);
+    if ((sim->flags & MCAMD_FLAG_LOG_SPACE) && (sim->flags & MCAMD_FLAG_PRODUCT_FORM))
+        return fail(MCAMD_ERR_INVALID, "MCAMD_FLAG_LOG_SPACE and MCAMD_FLAG_PRODUCT_FORM exclude each other");
     if (sim->path_offset + sim->n_paths_local < sim->path_offset)
         return fail(MCAMD_ERR_INVALID, "path_offset + n_paths_local overflows 64 bits");
     if (sim->precision == MCAMD_F64) {
@@ -138,6 +141,16 @@ mcamd::PathJob make_job(const mcamd_option *opt, const mcamd_sim *sim)
     // E[S_T] under the simulated dynamics: S_start exp(r * remaining time)
     j.control_mean = j.S_start * std::exp(opt->r * dt * static_cast<double>(j.n_sim));
     j.precision = sim->precision;
+    return j;
+}
+
+// The job of mcamd_price_paths[_enqueue]: a window-less job sums the log-returns and exponentiates once
+// (MCAMD_FLAG_LOG_SPACE's form) unless the caller asks for the product form; window jobs keep the product form unless
+// the caller asks for log space.
+mcamd::PathJob make_pricing_job(const mcamd_option *opt, const mcamd_sim *sim)
+{
+    mcamd::PathJob j = make_job(opt, sim);
+    if (!j.window && !(sim->flags & MCAMD_FLAG_PRODUCT_FORM)) j.logspace = true;
     return j;
 }
 
@@ -534,7 +547,7 @@ int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *
     zero_result(res);
     if (sim->n_paths_local == 0) return MCAMD_OK;  // empty shard: all-zero statistics
     HIP_TRY(hipSetDevice(ctx->device));
-    const mcamd::PathJob job = make_job(opt, sim);
+    const mcamd::PathJob job = make_pricing_job(opt, sim);
     const int rec = (job.vr & 2) ? 5 : 2;
     const uint32_t grid = mcamd::price_grid(job, ctx->compute_units);
     if (int rc = ensure_partials(ctx, grid, rec)) return rc;
@@ -559,7 +572,7 @@ int mcamd_price_paths_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mca
     if (!d_stats) return fail(MCAMD_ERR_INVALID, "d_stats is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     if (sim->n_paths_local == 0) return enqueue_empty(ctx, d_stats);
-    const mcamd::PathJob job = make_job(opt, sim);
+    const mcamd::PathJob job = make_pricing_job(opt, sim);
     const int rec = (job.vr & 2) ? 5 : 2;
     const uint32_t grid = mcamd::price_grid(job, ctx->compute_units);
     const Finish how = grid > mcamd::kFoldMaxRecords ? Finish::kReduce

@@ -472,7 +472,14 @@ def test_log_space_restart_and_price(ctx, oracle):
     big = ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(4_000_000, 252, capi.F64, flags=capi.FLAG_LOG_SPACE))
     assert abs(big.price - BS) <= 4 * big.std_err
     with pytest.raises(capi.McamdError):
-        ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(10, 2, capi.F64, flags=16))
+        ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(10, 2, capi.F64, flags=32))
+    with pytest.raises(capi.McamdError, match="exclude"):
+        ctx.price_paths(capi.make_option(**BENCH), capi.make_sim(10, 2, capi.F64, flags=capi.FLAG_LOG_SPACE | capi.FLAG_PRODUCT_FORM))
+    # a window-less job runs the log-space loop by default: the flag changes nothing there, the product form does
+    opt, s0 = capi.make_option(**BENCH), dict(n_paths=30_000, n_steps=40, precision=capi.F64, seed=6)
+    a, b = ctx.price_paths(opt, capi.make_sim(**s0)), ctx.price_paths(opt, capi.make_sim(**s0, flags=capi.FLAG_LOG_SPACE))
+    c = ctx.price_paths(opt, capi.make_sim(**s0, flags=capi.FLAG_PRODUCT_FORM))
+    assert a.sum == b.sum and a.sum != c.sum and math.isclose(a.sum, c.sum, rel_tol=1e-12)
 
 
 def test_log_space_nmc_matches_plain(ctx):
@@ -624,7 +631,11 @@ def test_store_terminal_row_is_bit_identical_to_in_register_path(ctx, prec):
     opt, sim = capi.make_option(**BENCH), capi.make_sim(n, steps, prec, seed=31)
     traj, pay = dev(n * steps, TORCH_T[prec]), dev(n, TORCH_T[prec])
     st = ctx.simulate_trajectories(opt, sim, traj, None, pay)
-    pr = ctx.price_paths(opt, sim)
+    # the product form carries the price itself, as the store kernel must; the default in-register loop sums the
+    # log-returns instead (same draws, rounding differs) and is compared below at its own tolerance
+    pr = ctx.price_paths(opt, capi.make_sim(n, steps, prec, seed=31, flags=capi.FLAG_PRODUCT_FORM))
+    dflt = ctx.price_paths(opt, sim)
+    assert math.isclose(dflt.sum, pr.sum, rel_tol=1e-12 if prec == capi.F64 else 1e-5) and dflt.sum != 0
     last = traj.view(steps, n)[-1]
     assert torch.equal(torch.clamp(last - 100.0, min=0.0), pay)
     assert math.isclose(st.sum, pr.sum, rel_tol=1e-13) and math.isclose(st.sumsq, pr.sumsq, rel_tol=1e-13)
@@ -1163,8 +1174,10 @@ def test_full_size_config3_properties(ctx):
     opt, sim = capi.make_option(**BENCH), capi.make_sim(n, steps, capi.F32, seed=1234)
     traj = dev(n * steps, torch.float32)
     st = ctx.simulate_trajectories(opt, sim, traj)
-    pr = ctx.price_paths(opt, sim)
+    pr = ctx.price_paths(opt, capi.make_sim(n, steps, capi.F32, seed=1234, flags=capi.FLAG_PRODUCT_FORM))
     assert math.isclose(st.sum, pr.sum, rel_tol=1e-13) and abs(st.price - BS) <= 4 * st.std_err
+    # the default in-register loop (sum of the log-returns, one exponential): same paths at fp32 rounding
+    assert math.isclose(ctx.price_paths(opt, sim).sum, pr.sum, rel_tol=RT[capi.F32])
     rows = traj.view(steps, n)
     last = rows[-1]
     assert math.isclose(torch.clamp(last - 100.0, min=0).double().sum().item(), pr.sum, rel_tol=1e-9)

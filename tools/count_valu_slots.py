@@ -152,9 +152,12 @@ def step_loop(asm: str, symbol: str, which: str = "shortest"):
 
 KERNELS = {
     # key: (source, mangled kernel, path-steps advanced per loop iteration)
-    "price_f64": ("price_f64.hip", "_ZN5mcamd12price_kernelIdLb0ELb0ELi0EEE", 2),
-    "price_f64_logspace": ("price_f64.hip", "_ZN5mcamd12price_kernelIdLb0ELb1ELi0EEE", 2),
-    "price_f32": ("price_f32.hip", "_ZN5mcamd12price_kernelIfLb0ELb0ELi0EEE", 4),
+    # window-less in-register pricing: the default loop sums the log-returns (LOGSPACE = true); the product form
+    # (MCAMD_FLAG_PRODUCT_FORM) multiplies the running price every step
+    "price_f64": ("price_f64.hip", "_ZN5mcamd12price_kernelIdLb0ELb1ELi0EEE", 2),
+    "price_f64_product": ("price_f64.hip", "_ZN5mcamd12price_kernelIdLb0ELb0ELi0EEE", 2),
+    "price_f32": ("price_f32.hip", "_ZN5mcamd12price_kernelIfLb0ELb1ELi0EEE", 4),
+    "price_f32_product": ("price_f32.hip", "_ZN5mcamd12price_kernelIfLb0ELb0ELi0EEE", 4),
     "store_f32": ("store.hip", "_ZN5mcamd12store_kernelIfLb0ELi0ELb1EEE", 16),
     # nested MC inner stage, fp64, barrier window (BASELINE configs[3]): St is evaluated at every step for the count
     # two step loops since the lane compaction (csrc/nmc_compact.hpp): batches of fresh paths (block index uniform) and

@@ -71,6 +71,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-store-roofline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--store-leg-first", action="store_true",
+                    help="run the configs[2] store leg right after the headline instead of after the sweep (diagnostic: "
+                         "does its time depend on what ran before it?)")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--no-nmc", action="store_true", help="skip the BASELINE configs[3] nested-MC side leg")
     ap.add_argument("--accuracy-pairs", type=int, default=1_000_000_000)
@@ -349,6 +352,47 @@ def cpu_nmc_baseline(opt_kw, n_paths, n_steps, n_inner, traj, cnt, budget_s=12.0
             "inner_path_steps_per_s": path_steps / dt, "host_cores_available": os.cpu_count() or 1}
 
 
+def store_leg(ctx, capi, torch, opt, position):
+    """Bandwidth-bound path beside the headline (N = 1 only): BASELINE configs[2], 100M paths x 252 steps fp32 stored
+    step-major with the payoff vector, 2 warm-up + 7 timed launches — and, alternating with them in the same process, the
+    same launch shape and store stream with nothing simulated (mcamd_diag_store_pattern): the HBM write ceiling of this
+    access pattern on THIS box at THIS moment, so the line tells a slow box from a slow kernel."""
+    try:
+        n3, s3 = 100_000_000, 252
+        free, _ = torch.cuda.mem_get_info()
+        if free <= n3 * s3 * 4 + (4 << 30):
+            return {"error": "not enough free HBM for the 100.8 GB trajectory buffer"}
+        buf = torch.empty(n3 * s3, dtype=torch.float32, device="cuda")
+        pay = torch.empty(n3, dtype=torch.float32, device="cuda")
+        sim3 = capi.make_sim(n3, s3, capi.F32, 1234)
+        for _ in range(2):   # first touches of a fresh 100.8 GB allocation are slower
+            ctx.simulate_trajectories(opt, sim3, buf, None, pay)
+        ks, cs = [], []
+        for i in range(7):
+            if i % 2 == 0:
+                cs.append(ctx.diag_store_pattern(n3, s3, capi.F32, buf, pay))
+            r3 = ctx.simulate_trajectories(opt, sim3, buf, None, pay)
+            ks.append(r3.kernel_ms)
+        kms, cms = sum(ks) / len(ks), sum(cs) / len(cs)
+        nbytes = n3 * s3 * 4 + n3 * 4 + 16 * r3.grid     # trajectories + payoff vector + block records: 101.2 GB
+        ach = nbytes / (kms / 1e3) / 1e9
+        out = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+               "traffic": pmc_traffic_bytes("store_kernel<float"), "kernel": "store_kernel<float,false,STEP_MAJOR,vec>",
+               "kernel_ms": kms, "kernel_ms_min": min(ks), "launches": len(ks),
+               "workload": "BASELINE configs[2]: 100M paths x 252 steps fp32 stored step-major + the payoff vector",
+               "algorithmic_bytes_per_launch": nbytes, "paths_per_s": n3 / (kms / 1e3),
+               "same_run_ceiling": {"what": "the same launch shape and store stream with nothing simulated "
+                                            "(mcamd_diag_store_pattern), alternating with the timed launches",
+                                    "kernel_ms": cms, "kernel_ms_min": min(cs), "launches": len(cs),
+                                    "GB_per_s": (n3 * s3 * 4 + n3 * 4) / (cms / 1e3) / 1e9},
+               "frac_of_same_run_store_ceiling": cms / kms, "leg_position": position,
+               "price": r3.price, "std_err": r3.std_err, "abs_err_vs_bs": abs(r3.price - BS_EXACT)}
+        del buf, pay
+        return out
+    except Exception as e:  # the headline must survive a failure of the side measurement
+        return {"error": str(e)}
+
+
 # ------------------------------------------------------------------------------------------------
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -568,6 +612,9 @@ def main(argv=None):
 
     solo = rank == 0 and world == 1
 
+    if solo and wl == "european252" and not args.no_store_roofline and args.store_leg_first:
+        line["roofline_store"] = store_leg(ctx, capi, torch, opt, "right after the headline")
+
     # the north-star sweep: 1M / 10M / 100M paths x 252 steps, in-register, both precisions.  Synchronous calls
     # (mcamd_price_paths): kernel_ms = HIP events around the simulation kernel, call_ms = host wall time of the whole
     # call (launches + final reduce + 16-byte copy + sync), so call_ms - kernel_ms is the per-call overhead.
@@ -607,34 +654,8 @@ def main(argv=None):
                                      "std_err": rl.std_err, "abs_err_vs_bs": abs(rl.price - BS_EXACT),
                                      "valu_slots_per_path_step": W.get("price_f64_product")}
 
-    # bandwidth-bound path, one untimed pass of configs[2] beside the headline (N=1 only)
-    if solo and wl == "european252" and not args.no_store_roofline:
-        try:
-            n3, s3 = 100_000_000, 252
-            free, _ = torch.cuda.mem_get_info()
-            if free > n3 * s3 * 4 + (4 << 30):
-                buf = torch.empty(n3 * s3, dtype=torch.float32, device="cuda")
-                pay = torch.empty(n3, dtype=torch.float32, device="cuda")
-                sim3 = capi.make_sim(n3, s3, capi.F32, 1234)
-                for _ in range(2):   # first touches of a fresh 100.8 GB allocation are slower
-                    ctx.simulate_trajectories(opt, sim3, buf, None, pay)
-                ks = []
-                for _ in range(7):
-                    r3 = ctx.simulate_trajectories(opt, sim3, buf, None, pay)
-                    ks.append(r3.kernel_ms)
-                kms = sum(ks) / len(ks)
-                nbytes = n3 * s3 * 4 + n3 * 4 + 16 * r3.grid     # trajectories + payoff vector + block records: 101.2 GB
-                ach = nbytes / (kms / 1e3) / 1e9
-                line["roofline_store"] = {
-                    "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                    "traffic": pmc_traffic_bytes("store_kernel<float"), "kernel": "store_kernel<float,false,STEP_MAJOR,vec>", "kernel_ms": kms,
-                    "kernel_ms_min": min(ks), "launches": len(ks),
-                    "workload": "BASELINE configs[2]: 100M paths x 252 steps fp32 stored step-major + the payoff vector",
-                    "algorithmic_bytes_per_launch": nbytes, "paths_per_s": n3 / (kms / 1e3),
-                    "price": r3.price, "std_err": r3.std_err, "abs_err_vs_bs": abs(r3.price - BS_EXACT)}
-                del buf, pay
-        except Exception as e:  # the headline must survive a failure of the side measurement
-            line["roofline_store"] = {"error": str(e)}
+    if solo and wl == "european252" and not args.no_store_roofline and not args.store_leg_first:
+        line["roofline_store"] = store_leg(ctx, capi, torch, opt, "after the sweep and the product-form leg")
 
     # "price within 1e-4 of closed form" on a 252-step BASELINE shape: the plain estimator would need > 2.6e10 paths
     # (sigma_payoff = 16.1), so this uses the engine's variance reduction — antithetic pairs + S_T control variate,

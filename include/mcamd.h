@@ -225,6 +225,14 @@ int mcamd_finalize_stats(const double stats[6], double r, double T, int control_
 int mcamd_simulate_trajectories(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout,
                                 void *d_traj, int32_t *d_counts, void *d_payoffs, mcamd_result *res);
 
+/* Diagnostic: mcamd_simulate_trajectories' launch shape and store stream (step-major rows, one 16-byte non-temporal
+ * store per lane per step, then the payoff row if d_payoffs != NULL) with nothing simulated: the HBM write ceiling of
+ * this access pattern on this device, measured beside the real kernel (bench.py roofline_store.same_run_ceiling).
+ * Requirements of the vector store path: n_paths_local a multiple of 4 (fp32) / 2 (fp64), 16-byte aligned buffers.
+ * kernel_ms: HIP-event time of the kernel.  The buffers are overwritten with a counter pattern. */
+int mcamd_diag_store_pattern(mcamd_ctx *ctx, uint64_t n_paths_local, uint32_t n_steps, int precision, void *d_traj,
+                             void *d_payoffs, float *kernel_ms);
+
 /* Array-driven pricer: normals are an input, d_normals[path * n_steps + step] (the reference's
  * layout), precision per sim->precision; d_payoffs (nullable): n_paths_local payoffs.
  * Replaces simulateOptionPriceGPU / simulateOptionPriceMultipleBlockGPU (array overloads)

@@ -26,7 +26,7 @@ EXPORTS = [
     "mcamd_memcpy_to_device", "mcamd_price_paths", "mcamd_price_paths_enqueue", "mcamd_enqueued_kernel_ms",
     "mcamd_finalize_stats", "mcamd_group_create", "mcamd_group_destroy", "mcamd_group_size",
     "mcamd_group_price_paths", "mcamd_group_ctx", "mcamd_group_shard", "mcamd_group_simulate_trajectories",
-    "mcamd_group_nmc_inner", "mcamd_group_nmc_fused", "mcamd_simulate_trajectories_enqueue", "mcamd_nmc_inner_enqueue",
+    "mcamd_group_nmc_inner", "mcamd_group_nmc_fused", "mcamd_simulate_trajectories_enqueue", "mcamd_diag_store_pattern", "mcamd_nmc_inner_enqueue",
     "mcamd_nmc_fused_enqueue", "mcamd_finalize_nmc_stats", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
     "mcamd_generate_normals", "mcamd_reduce_sum", "mcamd_nmc_inner", "mcamd_nmc_fused", "mcamd_finalize", "mcamd_finalize_cv", "mcamd_cnd_f32",
     "mcamd_bs_call_f32", "mcamd_bs_call_f64",
@@ -116,6 +116,7 @@ def load() -> C.CDLL:
                                                     C.POINTER(Result)]
     L.mcamd_group_nmc_inner.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, i32, pvp, pvp, pvp, C.POINTER(Result)]
     L.mcamd_group_nmc_fused.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), u64, i32, pvp, pvp, pvp, C.POINTER(Result)]
+    L.mcamd_diag_store_pattern.argtypes = [vp, u64, C.c_uint32, i32, vp, vp, C.POINTER(f32)]
     L.mcamd_price_from_normals.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), vp, vp, C.POINTER(Result)]
     L.mcamd_generate_normals.argtypes = [vp, u64, u64, i32, vp, C.POINTER(f32)]
     L.mcamd_reduce_sum.argtypes = [vp, vp, u64, i32, i32, C.POINTER(f64), C.POINTER(f32)]
@@ -275,6 +276,13 @@ class Context:
                           layout=STEP_MAJOR) -> None:
         _check(self._L.mcamd_nmc_fused_enqueue(self._h, C.byref(opt), C.byref(sim), outer_seed, layout, _ptr(prices),
                                                _ptr(counts), _ptr(point_prices), _ptr(stats)))
+
+    def diag_store_pattern(self, n_paths_local: int, n_steps: int, precision: int, traj, payoffs=None) -> float:
+        """kernel ms of the store kernel's pure store stream (diagnostic: the same-run HBM write ceiling)"""
+        ms = C.c_float(0)
+        _check(self._L.mcamd_diag_store_pattern(self._h, n_paths_local, n_steps, precision, _ptr(traj), _ptr(payoffs),
+                                                C.byref(ms)))
+        return ms.value
 
     def price_from_normals(self, opt: Option, sim: Sim, normals, payoffs=None) -> Result:
         res = Result()

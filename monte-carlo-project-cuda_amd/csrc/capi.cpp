@@ -685,6 +685,29 @@ int mcamd_simulate_trajectories(mcamd_ctx *ctx, const mcamd_option *opt, const m
     return finish_pricing(ctx, grid, 2, opt, sim, res);
 }
 
+int mcamd_diag_store_pattern(mcamd_ctx *ctx, uint64_t n_paths_local, uint32_t n_steps, int precision, void *d_traj,
+                             void *d_payoffs, float *kernel_ms)
+{
+    if (!ctx || !kernel_ms) return fail(MCAMD_ERR_INVALID, "ctx and kernel_ms must be non-NULL");
+    if (precision != MCAMD_F32 && precision != MCAMD_F64) return fail(MCAMD_ERR_INVALID, "bad precision %d", precision);
+    *kernel_ms = 0.0f;
+    const uint64_t v = precision == MCAMD_F32 ? 4 : 2;
+    if (n_paths_local == 0 || n_steps == 0) return MCAMD_OK;
+    if (!d_traj) return fail(MCAMD_ERR_INVALID, "d_traj is NULL");
+    if (n_paths_local % v != 0 || reinterpret_cast<uintptr_t>(d_traj) % 16 != 0 || reinterpret_cast<uintptr_t>(d_payoffs) % 16 != 0 ||
+        n_paths_local + v > 0xffffffffull / 8)
+        return fail(MCAMD_ERR_INVALID, "the store pattern is the vector store path's: n_paths_local a multiple of %llu (< 2^29), "
+                                       "16-byte aligned buffers", static_cast<unsigned long long>(v));
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t grid = mcamd::store_grid(n_paths_local, precision);
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(mcamd::launch_store_pattern(n_paths_local, n_steps, precision, d_traj, d_payoffs, grid, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    return MCAMD_OK;
+}
+
 int mcamd_price_from_normals(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, const void *d_normals,
                              void *d_payoffs, mcamd_result *res)
 {

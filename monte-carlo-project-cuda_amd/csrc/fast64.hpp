@@ -203,6 +203,16 @@ MC_HD double sqrt_scaled(double a, double k)
     return __builtin_fma(gk, t, gk);
 }
 
+// sqrt(a), a > 0 (same argument range and seed as sqrt_scaled, no scaling): five fp64 operations.
+MC_HD double sqrt_unclamped(double a)
+{
+    const double y = rsq_seed(a);
+    const double g = a * y;
+    const double e = __builtin_fma(-y, g, 1.0);
+    const double t = e * fma_usv(e, 0.375, 0.5);
+    return __builtin_fma(g, t, g);
+}
+
 // sin and cos of the Box-Muller angle pi * t, t = (v2 + 1) 2^-52 in (0, 2], straight from the two Philox words
 // (z, w) rocRAND builds v2 from (v2 = z ^ (w << 21) in the low word, w >> 11 above it: 53 bits).
 //   pi t = (2 pi / 512)(j + 1/2 + f),   j = v2 >> 44 (the top 9 bits of w),
@@ -234,6 +244,34 @@ MC_HD void sincos_bits(uint32_t z, uint32_t w, const D2 *tab, double &s, double 
     const double cd = __builtin_fma(ff, cp, 1.0);
     s = __builtin_fma(e.a, cd, e.b * sd);
     c = __builtin_fma(e.b, cd, -(e.a * sd));
+}
+
+// The sine alone, from a table ROTATED by an eighth of a turn (entry j holds {sin, cos} of arc j + N/8): with it
+// this returns sin(pi t + pi/4) = (sin(pi t) + cos(pi t)) / sqrt 2 — all a path needs of a Box-Muller pair when only
+// the SUM of its two normals matters (mc_device.hpp PairSum).  Same reduction and polynomials as sincos_bits, one
+// multiply and one fma fewer; cos_out (nullable at compile time through the template) is the cosine of that rotated
+// angle, for the callers that must split the pair after all (a path's odd last step).
+template <bool WANT_COS>
+MC_HD double sin_bits_rotated(uint32_t z, uint32_t w, const D2 *rot_tab, double *cos_out)
+{
+    const Split21 sw = split21(w);
+    const uint32_t lo = z ^ sw.shl21;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t hi;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(hi) : "v"(sw.shr11), "v"(0xfffu), "v"(0x43300000u));
+#else
+    const uint32_t hi = (sw.shr11 & 0xfffu) | 0x43300000u;
+#endif
+    const double f = fma_usv(make_double(lo, hi), 0x1p-44, 0x1p-44 - 256.5);
+    const D2 e = *reinterpret_cast<const D2 *>(reinterpret_cast<const char *>(rot_tab) + ((sw.shr11 >> 8) & 0x1ff0u));
+    const double ff = f * f;
+    double sp = fma_usv(ff, kSinF5, kSinF3);
+    sp = fma_vvs(ff, sp, kSinF1);
+    const double sd = f * sp;
+    const double cp = fma_usv(ff, kCosF4, kCosF2);
+    const double cd = __builtin_fma(ff, cp, 1.0);
+    if (WANT_COS) *cos_out = __builtin_fma(e.b, cd, -(e.a * sd));
+    return __builtin_fma(e.a, cd, e.b * sd);
 }
 
 // ---------------------------------------------------------------------------------------------

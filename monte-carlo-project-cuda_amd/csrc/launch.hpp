@@ -55,6 +55,11 @@ uint32_t store_grid(uint64_t n_local, int precision);
 hipError_t launch_store(const PathJob &job, int layout, void *d_traj, int32_t *d_counts, void *d_payoffs,
                         double *d_partials, uint32_t grid, hipStream_t stream);
 
+// diagnostic: the store kernel's shape (store_grid) and store stream with nothing simulated (n_local % (16 / sizeof(T)) == 0,
+// 16-byte aligned buffers, a row's bytes addressable with 32 bits)
+hipError_t launch_store_pattern(uint64_t n_local, uint32_t n_sim, int precision, void *d_traj, void *d_payoffs,
+                                uint32_t grid, hipStream_t stream);
+
 uint32_t array_grid(uint64_t n_local);
 hipError_t launch_from_normals(const PathJob &job, const void *d_normals, void *d_payoffs, double *d_partials,
                                uint32_t grid, hipStream_t stream);

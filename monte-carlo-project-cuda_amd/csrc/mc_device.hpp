@@ -111,6 +111,7 @@ __device__ __forceinline__ U4 philox_block(const PhiloxKeys &key, uint64_t subse
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 struct MathCtx {
+    template <bool ROTATED = false>
     __device__ __forceinline__ static MathCtx init() { return MathCtx{}; }
 };
 
@@ -122,6 +123,9 @@ struct MathCtx<double> {
     // the SIMD's arbiter serves the oldest wave first, and beside three or four older waves that keep the vector ALU
     // saturated a newly launched wave otherwise needs ~58 us for these thirty instructions (tools/init_probe.hip:
     // 1.4 us on an idle CU) — during which its workgroup holds LDS and registers without computing.
+    // ROTATED: the sin/cos table is copied rotated by an eighth of a turn (entry j = arc j + N/8), which is what the
+    // pair-sum loop (PairSum below) looks up; a kernel uses one form or the other, never both.
+    template <bool ROTATED = false>
     __device__ __forceinline__ static MathCtx init()
     {
         __builtin_amdgcn_s_setprio(3);
@@ -131,7 +135,8 @@ struct MathCtx<double> {
         __shared__ double s_exp_lo[256];
         for (int i = threadIdx.x; i < MCAMD_TAB_N; i += blockDim.x) {
             s_log[i] = f64::D2{kLogTab[i][0], kLogTab[i][1]};
-            s_sincos[i] = f64::D2{kSinCosTab[i][0], kSinCosTab[i][1]};
+            const int j = ROTATED ? ((i + MCAMD_TAB_N / 8) & (MCAMD_TAB_N - 1)) : i;
+            s_sincos[i] = f64::D2{kSinCosTab[j][0], kSinCosTab[j][1]};
         }
         for (int i = threadIdx.x; i < 256; i += blockDim.x) {
             s_exp_hi[i] = kExpHiTab[i];
@@ -332,6 +337,86 @@ struct Exponents<double> {
     }
 };
 
+// Sum of the normals of one Philox block, for the paths that need nothing else of them (a window-less path in log
+// space: ln(S_T / S_0) = n drift + vol (z_1 + ... + z_n)).  A Box-Muller pair is (r sin a, r cos a), so its sum is
+//     r (sin a + cos a) = sqrt(2) r sin(a + pi/4):
+// ONE trigonometric evaluation per pair instead of two, and no product with the radius per normal.  Every step
+// still draws its normal from the same Philox words; this is algebra on the pair, exact up to rounding (the sum
+// differs from adding rocRAND's two normals by about an ulp).  The sums are returned in units of kUnit so that the
+// constant factors fold into ONE multiplication at the end of the path:
+//     z_0 + ... + z_{NB-1} = kUnit * block(...),
+//     fp32: kUnit = sqrt(4 ln 2)  (r = sqrt(2 ln 2) sqrt(-log2 u); v_sin_f32 takes revolutions: + 1/8)
+//     fp64: kUnit = sqrt(2)       (the rotated sin/cos table of MathCtx<double>::init<true>)
+// head(n) is the sum of the block's FIRST n normals (n < NB: a path's last, partial block) in the same units.
+template <typename T>
+struct PairSum;
+
+template <>
+struct PairSum<float> {
+    static constexpr float kUnit = 1.6651092223153954f;   // sqrt(4 ln 2)
+    // sqrt(-log2 u) and the angle in revolutions of one pair (rocRAND's uniforms: 2^-32 + x 2^-32)
+    __device__ __forceinline__ static void polar(uint32_t a, uint32_t b, float shift, float &t, float &rev)
+    {
+        constexpr float k2pow32inv = 2.3283064365386963e-10f;
+        const float u = __builtin_fmaf(static_cast<float>(a), k2pow32inv, k2pow32inv);
+        rev = __builtin_fmaf(static_cast<float>(b), k2pow32inv, k2pow32inv + shift);
+        t = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));
+    }
+    __device__ __forceinline__ static float pair(uint32_t a, uint32_t b)
+    {
+        float t, rev;
+        polar(a, b, 0.125f, t, rev);
+        return t * __builtin_amdgcn_sinf(rev);
+    }
+    __device__ __forceinline__ static float block(const MathCtx<float> &, const PhiloxKeys &key, uint64_t subsequence,
+                                                   uint64_t block)
+    {
+        const U4 w = philox_block(key, subsequence, block);
+        return pair(w.x, w.y) + pair(w.z, w.w);
+    }
+    __device__ __forceinline__ static float head(const MathCtx<float> &, const PhiloxKeys &key, uint64_t subsequence,
+                                                  uint64_t block, uint32_t n)
+    {
+        constexpr float kInvSqrt2 = 0.70710678118654752f;
+        const U4 w = philox_block(key, subsequence, block);
+        float t, rev;
+        if (n == 1) {   // z0 alone: the sine member of the first pair
+            polar(w.x, w.y, 0.0f, t, rev);
+            return t * __builtin_amdgcn_sinf(rev) * kInvSqrt2;
+        }
+        float s = pair(w.x, w.y);
+        if (n == 3) {
+            polar(w.z, w.w, 0.0f, t, rev);
+            s = __builtin_fmaf(t * __builtin_amdgcn_sinf(rev), kInvSqrt2, s);
+        }
+        return s;
+    }
+};
+
+template <>
+struct PairSum<double> {
+    static constexpr double kUnit = 1.4142135623730951;   // sqrt(2)
+    __device__ __forceinline__ static double block(const MathCtx<double> &m, const PhiloxKeys &key, uint64_t subsequence,
+                                                    uint64_t block)
+    {
+        const U4 w = philox_block(key, subsequence, block);
+        const double u = f64::u53(w.x, w.y, 0x1p-53);
+        const double r = f64::sqrt_unclamped(f64::neg2log(u, m.t.log_tab));   // strictly positive argument (fast64.hpp)
+        return r * f64::sin_bits_rotated<false>(w.z, w.w, m.t.sincos_tab, nullptr);
+    }
+    // n == 1: z0 = r sin a = r (sin a' - cos a') / sqrt 2 with a' = a + pi/4 the rotated angle
+    __device__ __forceinline__ static double head(const MathCtx<double> &m, const PhiloxKeys &key, uint64_t subsequence,
+                                                   uint64_t block, uint32_t)
+    {
+        const U4 w = philox_block(key, subsequence, block);
+        const double u = f64::u53(w.x, w.y, 0x1p-53);
+        const double r = f64::sqrt_unclamped(f64::neg2log(u, m.t.log_tab));
+        double cs;
+        const double sn = f64::sin_bits_rotated<true>(w.z, w.w, m.t.sincos_tab, &cs);
+        return r * (0.5 * (sn - cs));
+    }
+};
+
 template <typename T, bool WINDOW>
 __device__ __forceinline__ T payoff(T St, int32_t count, const StepConsts<T> &c)
 {
@@ -396,7 +481,9 @@ __device__ __forceinline__ uint32_t window_open_lanes(int32_t count, int32_t cou
 
 // EARLY: leave the loop when the window has closed for the whole wavefront (off when the caller needs the
 // terminal price itself, i.e. for the S_T control variate).
-template <typename T, bool WINDOW, bool LOGSPACE, bool ANTI, bool EARLY = WINDOW>
+// PAIRSUM (window-less log-space paths of the pricing kernel only): add up Box-Muller pair sums (PairSum) instead of
+// single normals; the caller's MathCtx must then hold the rotated sin/cos table (MathCtx::init<true>).
+template <typename T, bool WINDOW, bool LOGSPACE, bool ANTI, bool EARLY = WINDOW, bool PAIRSUM = false>
 __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &seed,
                                                      uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
                                                      T log_start = T(0))
@@ -413,7 +500,13 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
     uint64_t live_steps = 0;   // up to 64 x n_sim
     // LOGSPACE: WINDOW ? ln(St/S_start) so far : sum of the normals so far (the twin's sum is its negative)
     T acc = WINDOW ? log_start : T(0), acc2 = acc;
-    if (LOGSPACE) {
+    static_assert(!PAIRSUM || (LOGSPACE && !WINDOW), "pair sums serve window-less log-space paths only");
+    if constexpr (PAIRSUM) {
+        // window-less path in log space: only the sum of the path's normals matters (PairSum); acc is that sum in
+        // units of PairSum<T>::kUnit.
+        for (uint32_t k = 0; k < n_full; ++k) acc += PairSum<T>::block(m, seed, subsequence, k);
+        if (rem) acc += PairSum<T>::head(m, seed, subsequence, n_full, rem);
+    } else if (LOGSPACE) {
         Normals<T> nrm;
         auto step = [&](T G) {
             if (WINDOW) {
@@ -493,8 +586,9 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
             if (ANTI) St2 = exp_of_logreturn(c.S_start, acc2, m);
         } else {
             const T S_in = St;
-            St = exp_of_logreturn(S_in, __builtin_fma(acc, c.vol, nd), m);
-            if (ANTI) St2 = exp_of_logreturn(S_in, __builtin_fma(-acc, c.vol, nd), m);
+            const T vol_unit = PAIRSUM ? c.vol * PairSum<T>::kUnit : c.vol;   // pair sums count in units of kUnit
+            St = exp_of_logreturn(S_in, fma_t(acc, vol_unit, nd), m);
+            if (ANTI) St2 = exp_of_logreturn(S_in, fma_t(-acc, vol_unit, nd), m);
         }
     }
     Sample<T> out;

@@ -43,7 +43,9 @@ __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *_
 {
     constexpr bool ANTI = (VR & 1) != 0, CV = (VR & 2) != 0;
     constexpr int N = CV ? 5 : 2;
-    const MathCtx<T> m = MathCtx<T>::init();
+    // the window-less log-space loop adds up pair sums and looks the sine up in the rotated table (PairSum)
+    constexpr bool PAIRSUM = LOGSPACE && !WINDOW;
+    const MathCtx<T> m = MathCtx<T>::template init<PAIRSUM>();
     const PhiloxKeys key = PhiloxKeys::make(a.seed);
     const StepConsts<T> c = resident(a.c);
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *_
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = 0.0;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_local; i += stride) {
-        const Sample<T> smp = simulate_sample<T, WINDOW, LOGSPACE, ANTI, WINDOW && !CV>(
+        const Sample<T> smp = simulate_sample<T, WINDOW, LOGSPACE, ANTI, WINDOW && !CV, PAIRSUM>(
             c, m, key, a.path_offset + i, c.S_start, c.Ik, c.n_sim);
         const double y = static_cast<double>(smp.pay);
         acc[0] += y;

@@ -153,6 +153,47 @@ __global__ __launch_bounds__(kBlock) void store_kernel(StoreArgs<T> a, double *_
     }
 }
 
+// Diagnostic: the store kernel's launch shape and store stream with nothing simulated — every thread writes its 16
+// bytes of every step row (non-temporal, scalar row base + 32-bit lane offset, as store_row does) and of the payoff
+// row, the value being a counter.  What it measures is the HBM write ceiling of THIS access pattern on THIS device at
+// the moment of the call; bench.py runs it beside the real kernel so that the line carries its own yardstick.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void store_pattern_kernel(T *__restrict__ traj, T *__restrict__ payoffs,
+                                                               uint64_t n_local, uint32_t n_sim)
+{
+    constexpr int V = 16 / sizeof(T);
+    using VT = T __attribute__((ext_vector_type(V)));
+    const uint64_t n_groups = n_local / V;   // whole 16-byte groups only (the launcher requires n_local % V == 0)
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; g < n_groups; g += stride) {
+        const uint32_t off = static_cast<uint32_t>(g * V);
+        VT v;
+#pragma unroll
+        for (int p = 0; p < V; ++p) v[p] = static_cast<T>(off + p);
+        for (uint32_t step = 0; step < n_sim; ++step) {
+            T *const row = traj + static_cast<uint64_t>(step) * n_local;   // wave-uniform
+            __builtin_nontemporal_store(v, reinterpret_cast<VT *>(reinterpret_cast<char *>(row) + off * static_cast<uint32_t>(sizeof(T))));
+#pragma unroll
+            for (int p = 0; p < V; ++p) v[p] += T(1);
+        }
+        if (payoffs)
+            __builtin_nontemporal_store(v, reinterpret_cast<VT *>(reinterpret_cast<char *>(payoffs) + off * static_cast<uint32_t>(sizeof(T))));
+    }
+}
+
+hipError_t launch_store_pattern(uint64_t n_local, uint32_t n_sim, int precision, void *d_traj, void *d_payoffs,
+                                uint32_t grid, hipStream_t stream)
+{
+    const dim3 g(grid), b(kBlock);
+    if (precision == 32)
+        hipLaunchKernelGGL(store_pattern_kernel<float>, g, b, 0, stream, static_cast<float *>(d_traj),
+                           static_cast<float *>(d_payoffs), n_local, n_sim);
+    else
+        hipLaunchKernelGGL(store_pattern_kernel<double>, g, b, 0, stream, static_cast<double *>(d_traj),
+                           static_cast<double *>(d_payoffs), n_local, n_sim);
+    return hipGetLastError();
+}
+
 uint32_t store_grid(uint64_t n_local, int precision)
 {
     const uint64_t v = precision == 32 ? 4 : 2;

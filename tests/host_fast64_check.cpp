@@ -27,6 +27,13 @@ int main(int argc, char **argv)
     const long n = argc > 1 ? std::atol(argv[1]) : 4000000;
     const Tables T{reinterpret_cast<const D2 *>(kLogTab), reinterpret_cast<const D2 *>(kSinCosTab), kExpHiTab, kExpLoTab};
     std::mt19937_64 gen(12345);
+    // the sin/cos table as the pair-sum loop holds it: rotated by an eighth of a turn (MathCtx<double>::init<true>)
+    static D2 rot[MCAMD_TAB_N];
+    for (int i = 0; i < MCAMD_TAB_N; ++i) {
+        const int j = (i + MCAMD_TAB_N / 8) & (MCAMD_TAB_N - 1);
+        rot[i] = D2{kSinCosTab[j][0], kSinCosTab[j][1]};
+    }
+    double e_squ = 0, e_rot = 0, e_rotc = 0, e_pair = 0;
     double e_log = 0, e_sqrt = 0, e_sin = 0, e_cos = 0, e_exp = 0, e_u = 0, e_prod = 0, e_wide = 0, e_sqs = 0, e_band = 0, e_pos = 0;
     const long double PI = 3.14159265358979323846264338327950288L;
     for (long i = 0; i < n; ++i) {
@@ -53,6 +60,7 @@ int main(int argc, char **argv)
             const double e = ulp_err(sqrt_scaled(aa, kk), static_cast<long double>(kk) * sqrtl(static_cast<long double>(aa)));
             if (e > e_sqs) e_sqs = e;
         }
+        if (aa > 0) { const double e = ulp_err(sqrt_unclamped(aa), sqrtl(static_cast<long double>(aa))); if (e > e_squ) e_squ = e; }
         uint32_t zz = z, ww = w;
         if (i % 13 == 0) { zz = 0xffffffffu; ww |= 0x7fffffu; }   // top of an arc: f = +1/2
         if (i % 17 == 0) { zz = 0; ww &= ~0x7fffffu; }            // bottom of an arc
@@ -66,6 +74,22 @@ int main(int argc, char **argv)
         const double ec = std::fabs(static_cast<double>(static_cast<long double>(cs) - cosl(ang)));
         if (es > e_sin) e_sin = es;
         if (ec > e_cos) e_cos = ec;
+        // the rotated-table sine: sin(a + pi/4) = (sin a + cos a) / sqrt 2, and the cosine of the same rotated angle
+        double rc;
+        const double rs = sin_bits_rotated<true>(zz, ww, rot, &rc);
+        const long double SQ2 = 1.41421356237309504880168872420969808L;
+        const double er = std::fabs(static_cast<double>(static_cast<long double>(rs) - (sinl(ang) + cosl(ang)) / SQ2));
+        const double erc = std::fabs(static_cast<double>(static_cast<long double>(rc) - (cosl(ang) - sinl(ang)) / SQ2));
+        if (er > e_rot) e_rot = er;
+        if (erc > e_rotc) e_rotc = erc;
+        if (sin_bits_rotated<false>(zz, ww, rot, nullptr) != rs) e_rot = 1.0;
+        // a whole pair sum as PairSum<double> forms it, against the sum of the two normals, relative to the radius
+        if (aa > 0) {
+            const double r = sqrt_unclamped(aa);
+            const long double want = sqrtl(want_a) * (sinl(ang) + cosl(ang));
+            const double ep = std::fabs(static_cast<double>(static_cast<long double>(r * rs) * SQ2 - want)) / (1.0 + static_cast<double>(sqrtl(want_a)));
+            if (ep > e_pair) e_pair = ep;
+        }
         // exp arguments: the GBM exponent range, plus a wide sweep
         const double xx = (i & 1) ? (static_cast<double>(static_cast<int64_t>(a)) * 0x1p-63) * 0.2
                                   : (static_cast<double>(static_cast<int64_t>(b)) * 0x1p-63) * 300.0;
@@ -119,6 +143,8 @@ int main(int argc, char **argv)
         if (!std::isinf(big) || tiny != 0.0) e_exp = 1e30;
     }
     std::printf("{\"n\": %ld, \"uniform_mismatch\": %g, \"neg2log_ulp\": %.3f, \"sqrt_ulp\": %.3f, \"sin_abs\": %.3g, "
-                "\"cos_abs\": %.3g, \"mul_exp_ulp\": %.3f, \"product252_ulp\": %.3f, \"mul_exp_wide_ulp_per_unit_x\": %.3f, \"sqrt_scaled_ulp\": %.3f, \"barrier_band_used\": %.4f, \"neg2log_nonpositive\": %g}\n", n, e_u, e_log, e_sqrt, e_sin, e_cos, e_exp, e_prod, e_wide, e_sqs, e_band, e_pos);
+                "\"cos_abs\": %.3g, \"mul_exp_ulp\": %.3f, \"product252_ulp\": %.3f, \"mul_exp_wide_ulp_per_unit_x\": %.3f, \"sqrt_scaled_ulp\": %.3f, \"barrier_band_used\": %.4f, \"neg2log_nonpositive\": %g, "
+                "\"sqrt_unclamped_ulp\": %.3f, \"sin_rotated_abs\": %.3g, \"cos_rotated_abs\": %.3g, \"pair_sum_rel\": %.3g}\n",
+                n, e_u, e_log, e_sqrt, e_sin, e_cos, e_exp, e_prod, e_wide, e_sqs, e_band, e_pos, e_squ, e_rot, e_rotc, e_pair);
     return 0;
 }

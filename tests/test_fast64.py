@@ -19,6 +19,11 @@ def test_fast64_accuracy_against_long_double_libm(tmp_path):
     assert r["sqrt_scaled_ulp"] <= 2.0                   # k sqrt(a) in six operations (one cubic step)
     assert r["neg2log_nonpositive"] == 0                 # -2 ln u > 0 for every u in (0, 1]: the radius needs no clamp
     assert r["sin_abs"] <= 2.5e-16 and r["cos_abs"] <= 2.5e-16
+    # the pair-sum loop of the window-less pricing kernel (mc_device.hpp PairSum): sqrt in five operations, the sine of
+    # the angle rotated by pi/4 from the rotated table, and a whole pair sum r sqrt2 sin(a + pi/4) against z0 + z1
+    assert r["sqrt_unclamped_ulp"] <= 2.0
+    assert r["sin_rotated_abs"] <= 2.5e-16 and r["cos_rotated_abs"] <= 2.5e-16
+    assert r["pair_sum_rel"] <= 6e-16
     assert r["mul_exp_ulp"] <= 4.5                       # one factor S e^x, |x| <= 1: 2 table entries + 3 multiplies
     assert r["mul_exp_wide_ulp_per_unit_x"] <= 3.5       # |x| up to 300: the error grows with the exponent's own ulp
     assert r["product252_ulp"] <= 64.0                   # 252-factor recurrence: rounding random-walks as sqrt(n)

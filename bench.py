@@ -47,6 +47,13 @@ BULLET = dict(B=120.0, P1=10, P2=50, use_window=1)     # hello.cu:11-13
 PEAK_VALU_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 78.6 Tlane-op/s (= 157.3 TFLOP/s fp32 FMA / 2)
 PEAK_HBM_GBS = 8000.0
 
+# Fixed yardsticks for the VALU-bound loops: the operation-count minimum of the scheme itself (DESIGN.md section 5 derives
+# them), in the same 2-cycle issue slots as W.  Unlike W — which is counted from whatever loop ships and falls when an
+# instruction is removed — these do not move with the implementation, so paths/s x W_FLOOR / peak only rises when the
+# kernel gets faster.  Window-less European path-step: Philox4x32-10 (17 multiplies + 17 three-input xors per block that
+# no hoisting removes) + the uniforms + -2 ln u + sqrt + ONE sine per Box-Muller pair + one accumulate.
+W_FLOOR = {"price_f64": 62.5, "price_f32": 22.5}
+
 METRIC = "MC paths/sec, European call (price error vs closed-form BS reported)"
 
 
@@ -217,13 +224,39 @@ def pmc_traffic_bytes(kernel_key: str):
     return None
 
 
-def valu_roofline(W, stale, key, kernel, lane_steps_per_s, traffic_key=None, extra=None):
+def pmc_valu_busy(kernel_key: str, build_id: str):
+    """Fraction of the elapsed cycles the vector ALUs spent issuing, for one kernel, from the committed PMC digest
+    (SQ_ACTIVE_INST_VALU x 4 / SIMDs over GRBM_GUI_ACTIVE / 8 XCDs, as profiles/README.md derives it) — only when the
+    digest was taken from the library that is loaded (it carries mcamd_build_id like the slot counts do)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    if d.get("build_id") != build_id:
+        return {"value": None, "stale": {"digest": os.path.basename(files[-1]), "digest_build_id": d.get("build_id"),
+                                         "library_build_id": build_id}}
+    for k, v in d.items():
+        if isinstance(v, dict) and kernel_key in k and v.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in v:
+            simds = 256 * 4
+            return {"value": (v["SQ_ACTIVE_INST_VALU"] * 4 / simds) / (v["GRBM_GUI_ACTIVE"] / 8),
+                    "digest": os.path.basename(files[-1]), "kernel": k}
+    return None
+
+
+def valu_roofline(W, stale, key, kernel, lane_steps_per_s, traffic_key=None, extra=None, build_id=None):
     w = W.get(key)
     rl = {"bound": "valu", "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
           "traffic": pmc_traffic_bytes(traffic_key) if traffic_key else None, "kernel": kernel,
           "path_steps_per_s_kernel": lane_steps_per_s, "valu_slots_per_path_step": w,
           "achieved": lane_steps_per_s * w / 1e12 if w else None,
           "frac": lane_steps_per_s * w / 1e12 / PEAK_VALU_TLANEOPS if w else None}
+    if key in W_FLOOR:   # the fixed yardstick: does not fall when an instruction is removed
+        rl["valu_slots_floor"] = W_FLOOR[key]
+        rl["frac_vs_floor"] = lane_steps_per_s * W_FLOOR[key] / 1e12 / PEAK_VALU_TLANEOPS
+    if traffic_key and build_id:
+        rl["valu_busy"] = pmc_valu_busy(traffic_key, build_id)
     det = W.get(key + "_detail")
     if w and det and det.get("measured_cost_cycles_per_iteration"):
         # the same instruction count priced with the per-instruction issue costs MEASURED on MI355X
@@ -608,7 +641,8 @@ def main(argv=None):
             line["roofline"] = valu_roofline(W, stale, "price_f64" if f64 else "price_f32",
                                              f"price_kernel<{'double' if f64 else 'float'},no window,log-space>",
                                              per_gpu * n_steps / avg_kernel_s,
-                                             "price_kernel<double" if f64 else "price_kernel<float")
+                                             "price_kernel<double, false, true, 0>" if f64 else "price_kernel<float, false, true, 0>",
+                                             build_id=capi.build_id())
 
     solo = rank == 0 and world == 1
 
@@ -635,6 +669,9 @@ def main(argv=None):
                 e = {"paths": n, "steps": 252, "dtype": "f64" if p_ == capi.F64 else "f32", "kernel_ms": k, "call_ms": c,
                      "call_over_kernel": c / k, "paths_per_s": n / (c / 1e3), "paths_per_s_kernel": n / (k / 1e3),
                      "roofline_frac": (n * 252 / (k / 1e3)) * w / 1e12 / PEAK_VALU_TLANEOPS if w else None,
+                     "roofline_frac_vs_floor": (n * 252 / (k / 1e3)) * W_FLOOR[key] / 1e12 / PEAK_VALU_TLANEOPS,
+                     # a wavefront runs whole paths: ceil(n / 64) wavefront-paths over 1024 SIMDs, the fullest SIMD sets the time
+                     "wave_quantization_ceiling": (n / 64 / 1024) / math.ceil(math.ceil(n / 64) / 1024),
                      "valu_slots_per_path_step": w, "price": r_.price, "std_err": r_.std_err,
                      "abs_err_vs_bs": abs(r_.price - BS_EXACT), "within_3se": abs(r_.price - BS_EXACT) <= 3 * r_.std_err}
                 sweep.append(e)

@@ -627,8 +627,8 @@ int mcamd_nmc_fused_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd
     if (sim->n_paths_local == 0) return enqueue_empty(ctx, d_stats);
     const uint32_t grid = mcamd::nmc_fused_grid(job);
     return enqueue_with_stats(ctx, grid, mcamd::kNmcRecord, static_cast<double>(job.n_points), d_stats, Finish::kReduce, [&] {
-        return mcamd::launch_nmc_fused(job, outer_seed, layout, d_prices, d_counts, d_point_prices, ctx->d_partials, grid,
-                                       ctx->stream);
+        return mcamd::launch_nmc_fused(job, outer_seed, layout, d_prices, d_counts, d_point_prices, ctx->d_partials,
+                                       ctx->d_queue, grid, ctx->stream);
     });
 }
 
@@ -797,8 +797,8 @@ int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
     const uint32_t grid = mcamd::nmc_fused_grid(job);
     if (int rc = ensure_partials(ctx, grid, mcamd::kNmcRecord)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    HIP_TRY(mcamd::launch_nmc_fused(job, outer_seed, layout, d_prices, d_counts, d_point_prices, ctx->d_partials, grid,
-                                    ctx->stream));
+    HIP_TRY(mcamd::launch_nmc_fused(job, outer_seed, layout, d_prices, d_counts, d_point_prices, ctx->d_partials,
+                                    ctx->d_queue, grid, ctx->stream));
     if (int rc = finish(ctx, grid, res, mcamd::kNmcRecord)) return rc;
     fill_nmc_result(res, job.n_points, grid);
     return MCAMD_OK;

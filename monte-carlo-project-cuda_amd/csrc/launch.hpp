@@ -92,7 +92,9 @@ hipError_t launch_nmc_inner(const NmcJob &job, int layout, int variant, const vo
                             hipStream_t stream);
 
 uint32_t nmc_fused_grid(const NmcJob &job);
+// d_queue: the context's 64-byte counter block (three of its words are this kernel's queues; zeroed on `stream`)
 hipError_t launch_nmc_fused(const NmcJob &job, uint64_t outer_seed, int layout, void *d_prices, int32_t *d_counts,
-                            void *d_point_prices, double *d_partials, uint32_t grid, hipStream_t stream);
+                            void *d_point_prices, double *d_partials, unsigned long long *d_queue, uint32_t grid,
+                            hipStream_t stream);
 
 }  // namespace mcamd

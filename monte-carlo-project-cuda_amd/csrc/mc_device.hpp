@@ -344,7 +344,7 @@ struct Exponents<double> {
 // still draws its normal from the same Philox words; this is algebra on the pair, exact up to rounding (the sum
 // differs from adding rocRAND's two normals by about an ulp).  The sums are returned in units of kUnit so that the
 // constant factors fold into ONE multiplication at the end of the path:
-//     z_0 + ... + z_{NB-1} = kUnit * block(...),
+//     z_0 + ... + z_{NB-1} = kUnit * (add_block(acc, ...) - acc),
 //     fp32: kUnit = sqrt(4 ln 2)  (r = sqrt(2 ln 2) sqrt(-log2 u); v_sin_f32 takes revolutions: + 1/8)
 //     fp64: kUnit = sqrt(2)       (the rotated sin/cos table of MathCtx<double>::init<true>)
 // head(n) is the sum of the block's FIRST n normals (n < NB: a path's last, partial block) in the same units.
@@ -368,11 +368,16 @@ struct PairSum<float> {
         polar(a, b, 0.125f, t, rev);
         return t * __builtin_amdgcn_sinf(rev);
     }
-    __device__ __forceinline__ static float block(const MathCtx<float> &, const PhiloxKeys &key, uint64_t subsequence,
-                                                   uint64_t block)
+    // acc + the block's sum (two fused multiply-adds)
+    __device__ __forceinline__ static float add_block(float acc, const MathCtx<float> &, const PhiloxKeys &key,
+                                                       uint64_t subsequence, uint64_t block)
     {
         const U4 w = philox_block(key, subsequence, block);
-        return pair(w.x, w.y) + pair(w.z, w.w);
+        float t1, r1, t2, r2;
+        polar(w.x, w.y, 0.125f, t1, r1);
+        polar(w.z, w.w, 0.125f, t2, r2);
+        acc = __builtin_fmaf(t1, __builtin_amdgcn_sinf(r1), acc);
+        return __builtin_fmaf(t2, __builtin_amdgcn_sinf(r2), acc);
     }
     __device__ __forceinline__ static float head(const MathCtx<float> &, const PhiloxKeys &key, uint64_t subsequence,
                                                   uint64_t block, uint32_t n)
@@ -396,13 +401,14 @@ struct PairSum<float> {
 template <>
 struct PairSum<double> {
     static constexpr double kUnit = 1.4142135623730951;   // sqrt(2)
-    __device__ __forceinline__ static double block(const MathCtx<double> &m, const PhiloxKeys &key, uint64_t subsequence,
-                                                    uint64_t block)
+    // acc + the block's sum (one fused multiply-add)
+    __device__ __forceinline__ static double add_block(double acc, const MathCtx<double> &m, const PhiloxKeys &key,
+                                                        uint64_t subsequence, uint64_t block)
     {
         const U4 w = philox_block(key, subsequence, block);
         const double u = f64::u53(w.x, w.y, 0x1p-53);
         const double r = f64::sqrt_unclamped(f64::neg2log(u, m.t.log_tab));   // strictly positive argument (fast64.hpp)
-        return r * f64::sin_bits_rotated<false>(w.z, w.w, m.t.sincos_tab, nullptr);
+        return __builtin_fma(r, f64::sin_bits_rotated<false>(w.z, w.w, m.t.sincos_tab, nullptr), acc);
     }
     // n == 1: z0 = r sin a = r (sin a' - cos a') / sqrt 2 with a' = a + pi/4 the rotated angle
     __device__ __forceinline__ static double head(const MathCtx<double> &m, const PhiloxKeys &key, uint64_t subsequence,
@@ -504,7 +510,7 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
     if constexpr (PAIRSUM) {
         // window-less path in log space: only the sum of the path's normals matters (PairSum); acc is that sum in
         // units of PairSum<T>::kUnit.
-        for (uint32_t k = 0; k < n_full; ++k) acc += PairSum<T>::block(m, seed, subsequence, k);
+        for (uint32_t k = 0; k < n_full; ++k) acc = PairSum<T>::add_block(acc, m, seed, subsequence, k);
         if (rem) acc += PairSum<T>::head(m, seed, subsequence, n_full, rem);
     } else if (LOGSPACE) {
         Normals<T> nrm;

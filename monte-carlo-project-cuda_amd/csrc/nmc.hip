@@ -243,16 +243,32 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
 
 // ---------------------------------------------------------------------------------------------
 // Fused outer + inner stage in ONE launch.  Replaces compute_nmc_one_block_per_point_with_outter
-// (inc/nmc.cuh:113-275): a workgroup first simulates and stores the outer paths it owns
-// (path = blockIdx.x + i * gridDim.x, one lane per owned path), then — after a workgroup barrier,
-// which is all that is needed because a workgroup only reads points it wrote itself — runs the
-// inner stage wave-per-point over exactly those points.  No grid-wide synchronisation, no second
-// launch.  Outer stream: (outer_seed, subsequence = global path id); inner stream as nmc_wave_kernel.
-// The stored arrays and the per-point prices are bit-identical to the two-launch route.
+// (inc/nmc.cuh:113-275).  A persistent grid; every wavefront works through two device-scope queues:
+//   stage 1  slices of 64 consecutive outer paths (one lane per path): simulate, store every (St, count), then
+//            publish — s_waitcnt vmcnt(0), agent-scope release fence, one atomic add on `done`;
+//   stage 2  once `done` has reached the number of slices (relaxed poll by lane 0 with s_sleep, then an agent-
+//            scope acquire fence by the polling wave, whose own loads follow it), the groups of the inner stage,
+//            exactly as nmc_wave_kernel pulls and prices them.
+// No grid-wide barrier and no assumption about residency: a wavefront enters stage 2 only when the stage-1 queue is
+// EMPTY, i.e. every slice has been TAKEN by a wavefront that is running and that waits for nothing while it
+// simulates its slice — so the count a stage-2 wavefront polls for is always reached, whether or not the whole grid
+// is resident (another process may hold part of the chip).  The wait happens once per wavefront, in the first
+// ~100 us of a launch that runs for ~0.2 s at BASELINE configs[3].
+// Outer stream: (outer_seed, subsequence = global path id); inner stream and pools as nmc_wave_kernel, so the
+// stored arrays and the per-point prices are bit-identical to the two-launch route.
+// (r02's form — a workgroup owned whole outer paths, simulated them, then priced only its own points behind a
+// workgroup barrier — needed no device-scope hand-off but left every workgroup with ~23 ms of private work: at the
+// end of the launch the last workgroups finished one by one, 225 ms against the two-launch route's 188.)
 // ---------------------------------------------------------------------------------------------
+struct FusedQueues {
+    unsigned long long *slices;   // stage-1 queue: next slice to simulate            (zero at launch)
+    unsigned long long *groups;   // stage-2 queue: next group to price               (zero at launch)
+    unsigned int *done;           // slices whose rows are stored and published        (zero at launch)
+};
+
 template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE>
 __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_t outer_seed, T *prices,
-                                                          int32_t *counts, double *__restrict__ partials)
+                                                          int32_t *counts, double *__restrict__ partials, FusedQueues q)
 {
     constexpr int kWaves = kBlock / kWave;
     constexpr int NB = Normals<T>::kPerBlock;
@@ -260,54 +276,69 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const StepConsts<T> c = resident(a.c);
-    // owned path groups (kPool adjacent paths each, the groups of nmc_wave_kernel): blockIdx.x, blockIdx.x + G, ...
-    const uint64_t groups_per_step = groups_per_step_of(a);
-    const int64_t lead = group_lead(a);
-    const uint64_t n_owned = groups_per_step > blockIdx.x ? (groups_per_step - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    auto next = [&](unsigned long long *counter) {   // one returning atomic per task, broadcast to the wavefront
+        unsigned long long first = 0;
+        if (lane == 0) first = atomicAdd(counter, 1ull);
+        return (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(first >> 32))) << 32) |
+               __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(first));
+    };
 
-    // ---- phase 1: outer trajectories of the owned paths (inc/nmc.cuh:144-202) ----
+    // ---- stage 1: outer trajectories (inc/nmc.cuh:144-202), one slice of 64 paths per wavefront at a time ----
+    const uint64_t n_slices = (a.n_local + kWave - 1) / kWave;
     {
-    const PhiloxKeys outer_key = PhiloxKeys::make(outer_seed);   // its 20 registers are free again after this phase
-    for (uint64_t i = threadIdx.x; i < n_owned * kPool; i += kBlock) {
-        const int64_t lpath = static_cast<int64_t>((blockIdx.x + (i / kPool) * gridDim.x) * kPool + i % kPool) - lead;
-        if (lpath < 0 || lpath >= static_cast<int64_t>(a.n_local)) continue;   // the shard's edge groups may be partial
-        const uint64_t path = static_cast<uint64_t>(lpath);
-        PathState<T> ps = PathState<T>::start(c.S_start);
-        int32_t cnt = c.Ik;
-        Exponents<T> ex;
-        for (uint32_t step = 0; step < a.n_steps; ++step) {
-            if (step % NB == 0) ex.fill(m, c, outer_key, a.path_offset + path, step / NB);
-            T x = ex.x[0];
+        const PhiloxKeys outer_key = PhiloxKeys::make(outer_seed);   // its 20 registers are free again after this stage
+        for (;;) {
+            const uint64_t sl = next(q.slices);
+            if (sl >= n_slices) break;
+            const uint64_t path = sl * kWave + lane;
+            if (path < a.n_local) {
+                PathState<T> ps = PathState<T>::start(c.S_start);
+                int32_t cnt = c.Ik;
+                Exponents<T> ex;
+                for (uint32_t step = 0; step < a.n_steps; ++step) {
+                    if (step % NB == 0) ex.fill(m, c, outer_key, a.path_offset + path, step / NB);
+                    T x = ex.x[0];
 #pragma unroll
-            for (int j = 1; j < NB; ++j) x = (step % NB == static_cast<uint32_t>(j)) ? ex.x[j] : x;
-            ps.step(x, m);
-            const T St = ps.value(m);
-            if (WINDOW) cnt += (c.B > St) ? 1 : 0;
-            const uint64_t idx = stored_index<T, LAYOUT>(a, step, path);
-            prices[idx] = St;
-            if (WINDOW) counts[idx] = cnt;
+                    for (int j = 1; j < NB; ++j) x = (step % NB == static_cast<uint32_t>(j)) ? ex.x[j] : x;
+                    ps.step(x, m);
+                    const T St = ps.value(m);
+                    if (WINDOW) cnt += (c.B > St) ? 1 : 0;
+                    const uint64_t idx = stored_index<T, LAYOUT>(a, step, path);
+                    prices[idx] = St;
+                    if (WINDOW) counts[idx] = cnt;
+                }
+            }
+            // publish the slice: every lane's stores have left the wavefront, the XCD's L2 is written back, then the count
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(q.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // ---- every slice has been taken; wait until they are all published (see the header: always reached) ----
+    {
+        unsigned int seen = 0;
+        do {
+            if (lane == 0) seen = __hip_atomic_load(q.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen = __builtin_amdgcn_readfirstlane(seen);
+            if (seen < n_slices) __builtin_amdgcn_s_sleep(32);
+        } while (seen < n_slices);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();  // workgroup-scope release/acquire: this workgroup reads only what it wrote
     const PhiloxKeys key = PhiloxKeys::make(a.seed);
 
-    // ---- phase 2: inner stage over the owned groups, one wavefront per group, long tasks first ----
-    double rec[kNmcRecord] = {0.0, 0.0, 0.0, 0.0};
-    const uint64_t n_tasks = n_owned * a.n_steps;
-    // the workgroup's wavefronts pull its tasks from a counter in LDS (same reason as nmc_wave_kernel's queue)
-    __shared__ unsigned int s_next;
+    // ---- stage 2: the inner stage, as nmc_wave_kernel ----
     __shared__ ParkedPaths<T, WINDOW> s_parked[kWaves];   // one buffer per wavefront (nmc_compact.hpp)
-    if (threadIdx.x == 0) s_next = 0;
-    __syncthreads();
+    double rec[kNmcRecord] = {0.0, 0.0, 0.0, 0.0};
+    const uint64_t groups_per_step = groups_per_step_of(a);
+    const uint64_t n_groups = groups_per_step * a.n_steps;   // step-major: the long tasks come first
+    const int64_t lead = group_lead(a);
     for (;;) {
-        unsigned int mine = 0;
-        if (lane == 0) mine = atomicAdd(&s_next, 1u);
-        const uint64_t task = __builtin_amdgcn_readfirstlane(mine);
-        if (task >= n_tasks) break;
-        const uint32_t step = static_cast<uint32_t>(task / n_owned);
-        const int64_t path0 =
-            static_cast<int64_t>((blockIdx.x + (task - static_cast<uint64_t>(step) * n_owned) * gridDim.x) * kPool) - lead;
+        const uint64_t g = next(q.groups);
+        if (g >= n_groups) break;
+        const uint32_t step = static_cast<uint32_t>(g / groups_per_step);
+        const int64_t path0 = static_cast<int64_t>((g - static_cast<uint64_t>(step) * groups_per_step) * kPool) - lead;
         price_group<T, WINDOW, LAYOUT, LOGSPACE>(a, c, m, key, prices, counts, step, path0, s_parked[wave], rec);
     }
     block_sumN<kBlock, kNmcRecord>(rec);
@@ -319,24 +350,28 @@ __global__ __launch_bounds__(kBlock) void nmc_fused_kernel(NmcArgs<T> a, uint64_
 
 uint32_t nmc_fused_grid(const NmcJob &job)
 {
-    // a workgroup owns whole groups of kPool outer paths; many small workgroups (one group each at BASELINE
-    // configs[3]) keep the end of the launch short, since a workgroup's work depends on when ITS paths' windows close
-    const uint64_t groups = (job.path.path_offset % kPool + job.path.n_local + kPool - 1) / kPool;
-    const uint64_t want = groups < 32768 ? groups : 32768;
+    // the same persistent grid as the wave-per-point kernel (its stage 2 IS that kernel), and never fewer workgroups
+    // than the outer stage has slices for: a slice is one wavefront's worth of outer paths
+    const uint64_t per_block = static_cast<uint64_t>(kBlock / kWave);
+    const uint64_t slices = (job.path.n_local + kWave - 1) / kWave;
+    const uint64_t need = (slices + per_block - 1) / per_block;
+    const uint64_t inner = nmc_grid(job, MCAMD_NMC_WAVE_PER_POINT);
+    const uint64_t resident = static_cast<uint64_t>(job.compute_units ? job.compute_units : 256) * 8;
+    const uint64_t want = inner > need ? inner : (need < resident ? need : resident);
     return static_cast<uint32_t>(want < 1 ? 1 : want);
 }
 
 template <typename T, bool WINDOW, int LAYOUT>
 static void launch_fused_variant(const NmcArgs<T> &a, uint64_t outer_seed, bool logspace, T *prices, int32_t *counts,
-                                 double *d_partials, uint32_t grid, hipStream_t stream)
+                                 double *d_partials, const FusedQueues &q, uint32_t grid, hipStream_t stream)
 {
     const dim3 g(grid), b(kBlock);
     if (logspace)
         hipLaunchKernelGGL((nmc_fused_kernel<T, WINDOW, LAYOUT, true>), g, b, 0, stream, a, outer_seed, prices, counts,
-                           d_partials);
+                           d_partials, q);
     else
         hipLaunchKernelGGL((nmc_fused_kernel<T, WINDOW, LAYOUT, false>), g, b, 0, stream, a, outer_seed, prices, counts,
-                           d_partials);
+                           d_partials, q);
 }
 
 uint32_t nmc_grid(const NmcJob &job, int variant)
@@ -389,27 +424,35 @@ static NmcArgs<T> make_args(const NmcJob &job, const void *d_prices, const int32
 
 template <typename T>
 static hipError_t launch_fused_t(const NmcJob &job, uint64_t outer_seed, int layout, void *d_prices, int32_t *d_counts,
-                                 void *d_point_prices, double *d_partials, uint32_t grid, hipStream_t stream)
+                                 void *d_point_prices, double *d_partials, const FusedQueues &q, uint32_t grid,
+                                 hipStream_t stream)
 {
     const NmcArgs<T> a = make_args<T>(job, d_prices, d_counts, d_point_prices);
     T *pr = static_cast<T *>(d_prices);
     const bool w = job.path.window, ls = job.path.logspace;
     if (layout == MCAMD_STEP_MAJOR) {
-        if (w) launch_fused_variant<T, true, MCAMD_STEP_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, grid, stream);
-        else launch_fused_variant<T, false, MCAMD_STEP_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, grid, stream);
+        if (w) launch_fused_variant<T, true, MCAMD_STEP_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, q, grid, stream);
+        else launch_fused_variant<T, false, MCAMD_STEP_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, q, grid, stream);
     } else {
-        if (w) launch_fused_variant<T, true, MCAMD_PATH_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, grid, stream);
-        else launch_fused_variant<T, false, MCAMD_PATH_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, grid, stream);
+        if (w) launch_fused_variant<T, true, MCAMD_PATH_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, q, grid, stream);
+        else launch_fused_variant<T, false, MCAMD_PATH_MAJOR>(a, outer_seed, ls, pr, d_counts, d_partials, q, grid, stream);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_nmc_fused(const NmcJob &job, uint64_t outer_seed, int layout, void *d_prices, int32_t *d_counts,
-                            void *d_point_prices, double *d_partials, uint32_t grid, hipStream_t stream)
+                            void *d_point_prices, double *d_partials, unsigned long long *d_queue, uint32_t grid,
+                            hipStream_t stream)
 {
+    // the context's 64-byte counter block: word 0 = stage-2 queue (as the wave kernel), bytes 16..19 = the pricing
+    // kernels' arrival ticket (zero between launches: left alone), word 3 = stage-1 queue, bytes 32..35 = `done`
+    hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(unsigned long long), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_queue + 3, 0, 2 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    const FusedQueues q{d_queue + 3, d_queue, reinterpret_cast<unsigned int *>(d_queue + 4)};
     return job.path.precision == 32
-               ? launch_fused_t<float>(job, outer_seed, layout, d_prices, d_counts, d_point_prices, d_partials, grid, stream)
-               : launch_fused_t<double>(job, outer_seed, layout, d_prices, d_counts, d_point_prices, d_partials, grid,
+               ? launch_fused_t<float>(job, outer_seed, layout, d_prices, d_counts, d_point_prices, d_partials, q, grid, stream)
+               : launch_fused_t<double>(job, outer_seed, layout, d_prices, d_counts, d_point_prices, d_partials, q, grid,
                                         stream);
 }
 

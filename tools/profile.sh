@@ -10,6 +10,7 @@ R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$R/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+python3 -c "import sys; sys.path.insert(0, '$R'); import importlib; print(importlib.import_module('monte-carlo-project-cuda_amd').capi.build_id())" > "$OUT/build_id.txt"
 case "$MODE" in
   default) BENCH=(python3 "$R/bench.py" --steps 40 --warmup 5 --no-cpu-baseline --no-accuracy --no-sweep --no-nmc) ;;
   nmc)     BENCH=(python3 "$R/bench.py" --workload nmc --steps 1 --warmup 1 --no-cpu-baseline) ;;
@@ -26,6 +27,6 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
  && timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_rd" -- "${BENCH[@]}" > "$OUT/pmc_rd.log" 2>&1
 rc=$?
 # keep the merge small: drop everything but csv + logs
-find "$OUT" -type f ! -name '*.csv' ! -name '*.log' -delete 2>/dev/null
+find "$OUT" -type f ! -name '*.csv' ! -name '*.log' ! -name 'build_id.txt' -delete 2>/dev/null
 echo "profile $TAG/$MODE rc=$rc"
 exit $rc

@@ -33,6 +33,12 @@ def main():
                 agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     out = {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"dispatches": max(len(v) for v in cs.values())}
            for k, cs in agg.items() if "kernel" in k}
+    # the library the counters were taken from (tools/profile.sh writes its mcamd_build_id beside the passes): bench.py
+    # quotes valu_busy from this digest only for that library
+    try:
+        out["build_id"] = open(os.path.join(src, "build_id.txt")).read().strip()
+    except OSError:
+        pass
     with open(os.path.join(dst, f"{tag}_pmc_per_kernel.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))

@@ -46,6 +46,15 @@ int main()
     black_scholes_CPU(closed_form, od.S0, od.K, od.T, od.r, od.v);
     std::cout << "\ncall Black Scholes : " << closed_form << std::endl;
 
+    // beyond the reference: the CPU pricers with a seed (the reference's are seeded from std::random_device), so that a
+    // test can hold the GPU prices against them at a fixed tolerance
+    const uint64_t cpu_seed = 1234;
+    float cpu_vanilla = 0.0f, cpu_bullet = 0.0f;
+    simulateOptionPriceCPU(&cpu_vanilla, od, &cpu_seed);
+    simulateBulletOptionPriceCPU(&cpu_bullet, od, &cpu_seed);
+    std::cout << "seeded CPU vanilla : " << cpu_vanilla << std::endl;
+    std::cout << "seeded CPU bullet : " << cpu_bullet << std::endl;
+
     // beyond the reference: fp64 paths with a standard error and a confidence interval
     const mcamd_result r = wrapper_gpu_option_vanilla_f64(od, 1);
     std::cout << "fp64 vanilla : " << r.price << " +- " << r.std_err << "  95% CI [" << r.ci_lo << ", " << r.ci_hi

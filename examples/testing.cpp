@@ -53,7 +53,12 @@ int main()
         std::cout << "Testing reduction: " << i << "\n";
         auto out = default_parameters.test_reduction(1, 1024, i);
         for (float el : out) std::cout << el << "\n";
-        expect(std::fabs(out[0] - truth) < 0.05f, "reduction equals host sum");
+        expect(out.size() == 1 && std::fabs(out[0] - truth) < 0.05f, "reduction equals host sum");
+        // several blocks: one partial per block (inc/testing.cuh:227-234), and the partials add up to the whole array
+        auto parts = default_parameters.test_reduction(7, 1024, i);
+        double total = 0.0;
+        for (float el : parts) total += el;
+        expect(parts.size() == 7 && std::fabs(total - truth) < 0.05, "block partials add up to the host sum");
     }
 
     test_outer(20, 150, 10, 555);

@@ -252,6 +252,15 @@ int mcamd_generate_normals(mcamd_ctx *ctx, uint64_t seed, uint64_t n, int precis
 int mcamd_reduce_sum(mcamd_ctx *ctx, const void *d_in, uint64_t n, int precision, int variant, double *sum,
                      float *kernel_ms);
 
+/* As mcamd_reduce_sum, but with the reference's launch shape and result shape: the schedule runs on n_blocks workgroups
+ * and h_partials (HOST, n_blocks doubles) receives one partial sum per workgroup, as reduce3..6 leave one float per
+ * block in g_odata for the caller to finish (inc/reduce.cuh:9-227; Simulation::test_reduction copies them back,
+ * inc/testing.cuh:185-235).  Unlike reduce3..5 — whose blocks cover 2 * blockDim elements each and nothing beyond
+ * n_blocks of those — every element is covered for any n_blocks (blocks stride over the array), so the partials
+ * always add up to the complete sum.  1 <= n_blocks <= 2^20. */
+int mcamd_reduce_partials(mcamd_ctx *ctx, const void *d_in, uint64_t n, int precision, int variant, uint32_t n_blocks,
+                          double *h_partials, float *kernel_ms);
+
 /* Nested Monte Carlo, inner stage: for every stored point (step, path) of the shard, n_paths_inner
  * continuation paths of n_steps - 1 - step steps from (d_prices, d_counts), windowed payoff, mean,
  * discount exp(-rT).  d_prices / d_counts are what mcamd_simulate_trajectories wrote (same layout
@@ -344,6 +353,18 @@ int mcamd_finalize(double sum, double sumsq, uint64_t n, double r, double T, mca
  * all-reduce over shards, or directly): price = exp(-rT) (ybar - beta cbar), beta = cov(y,c)/var(c),
  * std_err from the residual variance var(y)(1 - rho^2). */
 int mcamd_finalize_cv(const double sums[5], uint64_t n, double r, double T, mcamd_result *res);
+
+/* Host: the reference's serial CPU Monte Carlo (the baseline of BASELINE configs[0]), restated: fp32 paths and an fp32
+ * running sum, std::mt19937 + std::normal_distribution<float>, one draw per step in path order,
+ *   St *= expf((r - v^2/2) dt + v sqrtf(dt) G),   count += (St < B)  [use_window],   payoff max(St - K, 0) if the
+ *   window admits the count,   price = expf(-r T) * sum / n_paths.
+ * n_steps = 1 with use_window = 0 is simulateOptionPriceCPU (inc/tool.cuh:104-130); n_steps = N_STEPS with the window is
+ * simulateBulletOptionPriceCPU (inc/tool.cuh:133-173).  dt = opt->dt, or T / n_steps when that is 0.  The reference seeds
+ * from std::random_device and is not reproducible (inc/tool.cuh:116,151): from_random_device != 0 does the same; otherwise
+ * the generator is std::mt19937(seed), which makes the path testable.  payoff_sum (nullable) receives the undiscounted fp32
+ * sum.  This is the reference's CPU baseline, not a fallback: no GPU entry point ever routes here.  Single thread. */
+int mcamd_cpu_mc_f32(const mcamd_option *opt, uint64_t n_paths, uint32_t n_steps, uint64_t seed, int from_random_device,
+                     float *price, float *payoff_sum);
 
 /* Host closed form.  _f32 restates the reference's fp32 code path operation for operation
  * (CND: inc/BlackandScholes.hpp:8-30; black_scholes_CPU: :34-43); _f64 is the exact erfc form. */

@@ -3,10 +3,11 @@
 //   simulateOptionPriceCPU (array overload)     inc/testing.cuh:75-91  (deterministic CPU pricer)
 //   ReductionType                               inc/testing.cuh:100-106
 //   class Simulation                            inc/testing.cuh:108-405
-// Differences: device buffers are released in the destructor (the reference leaks them); reductions
-// return the complete sum in element 0 followed by nothing else (the reference returns one partial per
-// block and its test launches a single block, testing.cu:82-88); trajectories come back in the
-// reference's path-major order [trajectory * n_steps + step].
+// Differences: device buffers are released in the destructor (the reference leaks them); test_reduction
+// returns one partial per block like the reference (inc/testing.cuh:227-234; testing.cu:82-88 prints them
+// one by one), but the partials always add up to the sum of the whole array, whatever n_blocks is (the
+// reference's reduce3..5 blocks read 2 * blockDim elements each and nothing beyond); trajectories come back
+// in the reference's path-major order [trajectory * n_steps + step].
 #pragma once
 
 #include "tool.hpp"
@@ -96,14 +97,18 @@ public:
         return out;
     }
 
-    // Sum of the device random array with the chosen schedule; element 0 is the complete sum.
-    std::vector<float> test_reduction(size_t /*n_blocks*/, size_t /*n_threads_per_block*/, int reduction)
+    // Block sums of the device random array with the chosen schedule on n_blocks workgroups: one partial per
+    // block, as the reference returns (inc/testing.cuh:185-235); their sum is the sum of the whole array.
+    // n_threads_per_block is accepted and ignored (the engine's workgroups are 256 threads).
+    std::vector<float> test_reduction(size_t n_blocks, size_t /*n_threads_per_block*/, int reduction)
     {
-        double sum = 0.0;
+        if (n_blocks == 0) n_blocks = 1;
+        std::vector<double> partials(n_blocks, 0.0);
         mcamd_ctx *ctx = mcamd_shim::context();
-        if (!ctx || mcamd_reduce_sum(ctx, d_random_array, length(), MCAMD_F32, reduction, &sum, nullptr))
+        if (!ctx || mcamd_reduce_partials(ctx, d_random_array, length(), MCAMD_F32, reduction,
+                                          static_cast<uint32_t>(n_blocks), partials.data(), nullptr))
             std::fprintf(stderr, "mcamd error: %s\n", mcamd_last_error());
-        return {static_cast<float>(sum)};
+        return std::vector<float>(partials.begin(), partials.end());
     }
 
     std::vector<float> simulate_trajectory_cpu()

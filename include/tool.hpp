@@ -106,27 +106,19 @@ inline mcamd_sim to_sim(uint64_t n_paths, uint32_t n_steps, uint64_t seed, int p
     return s;
 }
 
-// Serial CPU Monte Carlo in fp32 with std::mt19937 + std::normal_distribution<float>, seeded from
-// std::random_device like the reference (so it is not reproducible run to run).  n_steps == 1 with
-// window == false is the one-step vanilla pricer.
-inline float cpu_monte_carlo(const OptionData &od, int n_steps, float dt, bool window)
+// Serial CPU Monte Carlo (inc/tool.cuh:104-173) through mcamd_cpu_mc_f32: fp32, std::mt19937 +
+// std::normal_distribution<float>.  seed == nullptr seeds from std::random_device like the reference (not
+// reproducible run to run); a seed makes the run repeatable, so a driver can compare GPU and CPU prices at a
+// fixed tolerance.  n_steps == 1 with window == false is the one-step vanilla pricer.
+inline float cpu_monte_carlo(const OptionData &od, int n_steps, float dt, bool window, const uint64_t *seed = nullptr)
 {
-    std::mt19937 gen(std::random_device{}());
-    std::normal_distribution<float> gauss(0.0f, 1.0f);
-    const float drift = (od.r - (od.v * od.v) / 2) * dt;
-    const float vol = od.v * std::sqrt(dt);
-    float acc = 0.0f;
-    for (int p = 0; p < od.N_PATHS; ++p) {
-        float s = od.S0;
-        int below = 0;
-        for (int k = 0; k < n_steps; ++k) {
-            s *= std::exp(drift + vol * gauss(gen));
-            below += (window && s < od.B) ? 1 : 0;
-        }
-        const bool pays = !window || (below >= od.P1 && below <= od.P2);
-        if (pays && s > od.K) acc += s - od.K;
-    }
-    return std::exp(-od.r * od.T) * acc / static_cast<float>(od.N_PATHS);
+    mcamd_option o = to_option(od, window, n_steps > 1);
+    o.dt = dt;
+    float price = -1.0f;
+    if (mcamd_cpu_mc_f32(&o, static_cast<uint64_t>(od.N_PATHS), static_cast<uint32_t>(n_steps), seed ? *seed : 0,
+                         seed == nullptr, &price, nullptr) != MCAMD_OK)
+        std::fprintf(stderr, "mcamd error: %s\n", mcamd_last_error());
+    return price;
 }
 
 }  // namespace mcamd_shim
@@ -161,14 +153,15 @@ inline void getDeviceProperty()
     std::printf("Number of compute units: %d\n", di.compute_units);
 }
 
-inline void simulateOptionPriceCPU(float *optionPriceCPU, OptionData option_data)
+// The reference's signatures, plus an optional seed (nullptr = std::random_device, as the reference).
+inline void simulateOptionPriceCPU(float *optionPriceCPU, OptionData option_data, const uint64_t *seed = nullptr)
 {
-    *optionPriceCPU = mcamd_shim::cpu_monte_carlo(option_data, 1, option_data.T, false);
+    *optionPriceCPU = mcamd_shim::cpu_monte_carlo(option_data, 1, option_data.T, false, seed);
 }
 
-inline void simulateBulletOptionPriceCPU(float *optionPriceCPU, OptionData option_data)
+inline void simulateBulletOptionPriceCPU(float *optionPriceCPU, OptionData option_data, const uint64_t *seed = nullptr)
 {
-    *optionPriceCPU = mcamd_shim::cpu_monte_carlo(option_data, option_data.N_STEPS, option_data.step, true);
+    *optionPriceCPU = mcamd_shim::cpu_monte_carlo(option_data, option_data.N_STEPS, option_data.step, true, seed);
 }
 
 // The reference sizes its grid by how many curandState fit in 90% of free memory.  There is no

@@ -28,7 +28,7 @@ EXPORTS = [
     "mcamd_group_price_paths", "mcamd_group_ctx", "mcamd_group_shard", "mcamd_group_simulate_trajectories",
     "mcamd_group_nmc_inner", "mcamd_group_nmc_fused", "mcamd_simulate_trajectories_enqueue", "mcamd_diag_store_pattern", "mcamd_nmc_inner_enqueue",
     "mcamd_nmc_fused_enqueue", "mcamd_finalize_nmc_stats", "mcamd_simulate_trajectories", "mcamd_price_from_normals",
-    "mcamd_generate_normals", "mcamd_reduce_sum", "mcamd_nmc_inner", "mcamd_nmc_fused", "mcamd_finalize", "mcamd_finalize_cv", "mcamd_cnd_f32",
+    "mcamd_generate_normals", "mcamd_reduce_sum", "mcamd_reduce_partials", "mcamd_cpu_mc_f32", "mcamd_nmc_inner", "mcamd_nmc_fused", "mcamd_finalize", "mcamd_finalize_cv", "mcamd_cnd_f32",
     "mcamd_bs_call_f32", "mcamd_bs_call_f64",
 ]
 
@@ -120,6 +120,8 @@ def load() -> C.CDLL:
     L.mcamd_price_from_normals.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), vp, vp, C.POINTER(Result)]
     L.mcamd_generate_normals.argtypes = [vp, u64, u64, i32, vp, C.POINTER(f32)]
     L.mcamd_reduce_sum.argtypes = [vp, vp, u64, i32, i32, C.POINTER(f64), C.POINTER(f32)]
+    L.mcamd_reduce_partials.argtypes = [vp, vp, u64, i32, i32, C.c_uint32, C.POINTER(f64), C.POINTER(f32)]
+    L.mcamd_cpu_mc_f32.argtypes = [C.POINTER(Option), u64, C.c_uint32, u64, i32, C.POINTER(f32), C.POINTER(f32)]
     L.mcamd_nmc_inner.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), i32, i32, vp, vp, vp, C.POINTER(Result)]
     L.mcamd_nmc_fused.argtypes = [vp, C.POINTER(Option), C.POINTER(Sim), u64, i32, vp, vp, vp, C.POINTER(Result)]
     L.mcamd_finalize.argtypes = [f64, f64, u64, f64, f64, C.POINTER(Result)]
@@ -188,6 +190,13 @@ def finalize_nmc_stats(stats6) -> Result:
     arr = (C.c_double * 6)(*[float(x) for x in stats6])
     _check(load().mcamd_finalize_nmc_stats(arr, C.byref(res)))
     return res
+
+
+def cpu_mc_f32(opt: Option, n_paths: int, n_steps: int, seed: int = 0, from_random_device: bool = False):
+    """(price, undiscounted fp32 payoff sum) of the reference's serial CPU Monte Carlo (mcamd_cpu_mc_f32)"""
+    p, s = C.c_float(0), C.c_float(0)
+    _check(load().mcamd_cpu_mc_f32(C.byref(opt), n_paths, n_steps, seed, int(from_random_device), C.byref(p), C.byref(s)))
+    return p.value, s.value
 
 
 def cnd_f32(x):
@@ -299,6 +308,12 @@ class Context:
         s, ms = C.c_double(0), C.c_float(0)
         _check(self._L.mcamd_reduce_sum(self._h, _ptr(x), n, precision, variant, C.byref(s), C.byref(ms)))
         return s.value, ms.value
+
+    def reduce_partials(self, x, n: int, precision: int, variant: int, n_blocks: int):
+        """one partial sum per workgroup (they add up to the complete sum) and the kernel's ms"""
+        arr, ms = (C.c_double * n_blocks)(), C.c_float(0)
+        _check(self._L.mcamd_reduce_partials(self._h, _ptr(x), n, precision, variant, n_blocks, arr, C.byref(ms)))
+        return list(arr), ms.value
 
     def nmc_inner(self, opt: Option, sim: Sim, prices, counts, point_prices, layout=STEP_MAJOR,
                   variant=NMC_WAVE_PER_POINT) -> Result:

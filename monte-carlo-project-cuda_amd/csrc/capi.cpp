@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <random>
 #include <string>
 
 static_assert(sizeof(mcamd_option) == 88 && sizeof(mcamd_sim) == 48 && sizeof(mcamd_result) == 128 &&
@@ -801,6 +802,63 @@ int mcamd_nmc_fused(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *si
                                     ctx->d_queue, grid, ctx->stream));
     if (int rc = finish(ctx, grid, res, mcamd::kNmcRecord)) return rc;
     fill_nmc_result(res, job.n_points, grid);
+    return MCAMD_OK;
+}
+
+int mcamd_reduce_partials(mcamd_ctx *ctx, const void *d_in, uint64_t n, int precision, int variant, uint32_t n_blocks,
+                          double *h_partials, float *kernel_ms)
+{
+    if (!ctx || !h_partials) return fail(MCAMD_ERR_INVALID, "ctx and h_partials must be non-NULL");
+    if (precision != MCAMD_F32 && precision != MCAMD_F64) return fail(MCAMD_ERR_INVALID, "bad precision %d", precision);
+    if (variant < MCAMD_REDUCE_SEQUENTIAL || variant > MCAMD_REDUCE_GRID_STRIDE)
+        return fail(MCAMD_ERR_INVALID, "reduce variant must be 3..6 (ReductionType), got %d", variant);
+    if (n_blocks == 0 || n_blocks > mcamd::kMaxGrid) return fail(MCAMD_ERR_INVALID, "n_blocks must be in [1, 2^20]");
+    if (kernel_ms) *kernel_ms = 0.0f;
+    for (uint32_t b = 0; b < n_blocks; ++b) h_partials[b] = 0.0;
+    if (n == 0) return MCAMD_OK;
+    if (!d_in) return fail(MCAMD_ERR_INVALID, "d_in is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = ensure_partials(ctx, n_blocks)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(mcamd::launch_reduce(d_in, n, precision, variant, ctx->d_partials, n_blocks, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    // the kernels leave records of two doubles {partial, 0}: strided copy of the first of each
+    HIP_TRY(hipMemcpy2DAsync(h_partials, sizeof(double), ctx->d_partials, 2 * sizeof(double), sizeof(double), n_blocks,
+                             hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    return MCAMD_OK;
+}
+
+int mcamd_cpu_mc_f32(const mcamd_option *opt, uint64_t n_paths, uint32_t n_steps, uint64_t seed, int from_random_device,
+                     float *price, float *payoff_sum)
+{
+    if (!opt || !price) return fail(MCAMD_ERR_INVALID, "opt and price must be non-NULL");
+    if (n_steps == 0) return fail(MCAMD_ERR_INVALID, "n_steps must be >= 1");
+    *price = 0.0f;
+    if (payoff_sum) *payoff_sum = 0.0f;
+    if (n_paths == 0) return MCAMD_OK;
+    // fp32 throughout, the operation order of inc/tool.cuh:104-173
+    const float K = static_cast<float>(opt->K), r = static_cast<float>(opt->r), sigma = static_cast<float>(opt->v);
+    const float S0 = static_cast<float>(opt->S0), T = static_cast<float>(opt->T), B = static_cast<float>(opt->B);
+    const float dt = opt->dt > 0.0 ? static_cast<float>(opt->dt) : T / static_cast<float>(n_steps);
+    const float sqrdt = sqrtf(dt);
+    const float P1 = static_cast<float>(opt->P1), P2 = static_cast<float>(opt->P2);   // the reference compares as floats
+    std::mt19937 generator(from_random_device ? std::random_device{}() : static_cast<std::mt19937::result_type>(seed));
+    std::normal_distribution<float> distribution(0.0f, 1.0f);
+    float sum = 0.0f;
+    for (uint64_t i = 0; i < n_paths; ++i) {
+        float St = S0;
+        int count = 0;
+        for (uint32_t j = 0; j < n_steps; ++j) {
+            const float G = distribution(generator);
+            St *= expf((r - (sigma * sigma) / 2) * dt + sigma * sqrdt * G);
+            if (opt->use_window && St < B) count++;
+        }
+        if (!opt->use_window || (count >= P1 && count <= P2)) sum += std::fmax(St - K, 0.0f);
+    }
+    if (payoff_sum) *payoff_sum = sum;
+    *price = expf(-r * T) * sum / static_cast<float>(n_paths);
     return MCAMD_OK;
 }
 

@@ -116,3 +116,52 @@ def test_product_does_not_reach_into_the_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                     text = open(os.path.join(d, f)).read()
                     assert "pyoracle" not in text and "liboracle" not in text and "oracle/" not in text, (d, f)
+
+
+def test_cpu_mc_f32_is_the_reference_arithmetic_bit_for_bit(lib, oracle):
+    """mcamd_cpu_mc_f32 restates inc/tool.cuh:104-173 with a seed.  The reference's own build (oracle/_ref) holds the same
+    recurrence with the normals as an input (inc/testing.cuh:75-91) and the std::mt19937 / std::normal_distribution<float>
+    stream: feeding one into the other must reproduce the seeded pricer's fp32 payoff sum exactly."""
+    ref = oracle.ref_cpumc()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    for n, steps, seed in ((1000, 1, 7), (257, 12, 1234), (64, 100, 99)):
+        normals = np.zeros(n * steps, dtype=np.float32)
+        ref.ref_mt19937_normals(seed, n * steps, normals.ctypes.data_as(C.POINTER(C.c_float)))
+        pay = np.zeros(n, dtype=np.float32)
+        dt = np.float32(1.0) / np.float32(steps)
+        ref.ref_simulateOptionPriceCPU_array.restype = C.c_float
+        mean = ref.ref_simulateOptionPriceCPU_array(n, steps, normals.ctypes.data_as(C.POINTER(C.c_float)), 100.0, 0.2,
+                                                    float(np.sqrt(dt)), 0.1, 100.0, float(dt),
+                                                    pay.ctypes.data_as(C.POINTER(C.c_float)))
+        price, total = capi.cpu_mc_f32(capi.make_option(), n, steps, seed)
+        want_total = np.float32(0.0)
+        for p_ in pay:
+            want_total = np.float32(want_total + p_)
+        assert np.float32(total) == want_total and total > 0
+        assert np.float32(total) / np.float32(n) == np.float32(mean)
+        assert np.float32(price) == np.float32(np.exp(np.float32(-0.1)) * want_total / np.float32(n)) or \
+            abs(price - math.exp(-0.1) * float(want_total) / n) < 1e-5 * price
+    # window: a bullet job against a plain-python restatement on the same stream
+    opt = capi.make_option(B=101.0, P1=2, P2=7, use_window=1)
+    n, steps, seed = 50, 10, 5
+    normals = np.zeros(n * steps, dtype=np.float32)
+    ref.ref_mt19937_normals(seed, n * steps, normals.ctypes.data_as(C.POINTER(C.c_float)))
+    f = np.float32
+    dt = f(1.0) / f(steps)
+    drift, vol = (f(0.1) - (f(0.2) * f(0.2)) / f(2)) * dt, f(0.2) * np.sqrt(dt, dtype=np.float32)
+    total = f(0.0)
+    for i in range(n):
+        st, cnt = f(100.0), 0
+        for j in range(steps):
+            st = f(st * np.exp(f(drift + f(vol * normals[i * steps + j])), dtype=np.float32))
+            cnt += 1 if st < f(101.0) else 0
+        if 2 <= cnt <= 7:
+            total = f(total + max(f(st - f(100.0)), f(0.0)))
+    price, got = capi.cpu_mc_f32(opt, n, steps, seed)
+    assert abs(got - float(total)) <= 2e-5 * max(1.0, float(total))      # numpy's expf vs libm's: an ulp here and there
+    # unseeded = std::random_device, like the reference: two runs differ, both near the closed form
+    a, _ = capi.cpu_mc_f32(capi.make_option(), 200_000, 1, 0, True)
+    b, _ = capi.cpu_mc_f32(capi.make_option(), 200_000, 1, 0, True)
+    assert a != b and abs(a - 13.2697) < 0.2 and abs(b - 13.2697) < 0.2
+    assert capi.cpu_mc_f32(capi.make_option(), 0, 1, 1)[0] == 0.0

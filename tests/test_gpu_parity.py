@@ -670,6 +670,30 @@ def test_reduce_sum_vs_host_fp64(ctx, variant, prec, n):
 
 
 @pytest.mark.parametrize("variant", [3, 4, 5, 6])
+@pytest.mark.parametrize("prec", [capi.F32, capi.F64])
+def test_reduce_partials_one_per_block_adding_up_to_the_sum(ctx, variant, prec):
+    # the reference's result shape (one partial per block left for the caller, inc/testing.cuh:227-234): whatever
+    # n_blocks is, the partials add up to the sum of the WHOLE array (reduce3..5 of the reference cover only
+    # n_blocks * 2 * blockDim elements)
+    g = torch.Generator(device="cpu").manual_seed(variant)
+    for n in (1, 1000, 102_400, 1_000_003):
+        x = torch.randn(n, generator=g, dtype=TORCH_T[prec])
+        xd, want = x.cuda(), float(x.double().sum())
+        for n_blocks in (1, 7, 100, 1024):
+            parts, ms = ctx.reduce_partials(xd, n, prec, variant, n_blocks)
+            assert len(parts) == n_blocks and ms >= 0
+            assert math.isclose(math.fsum(parts), want, rel_tol=1e-12, abs_tol=1e-9 * math.sqrt(n))
+            if n_blocks > 1 and n >= 102_400:
+                assert sum(1 for p_ in parts if p_ != 0.0) > 1       # the work really is spread over the blocks
+        one, _ = ctx.reduce_partials(xd, n, prec, variant, 1)
+        total, _ = ctx.reduce_sum(xd, n, prec, variant)
+        assert math.isclose(one[0], total, rel_tol=1e-12, abs_tol=1e-9 * math.sqrt(n))
+    assert ctx.reduce_partials(None, 0, prec, variant, 3)[0] == [0.0, 0.0, 0.0]
+    with pytest.raises(capi.McamdError):
+        ctx.reduce_partials(xd, n, prec, variant, 0)
+
+
+@pytest.mark.parametrize("variant", [3, 4, 5, 6])
 def test_reduce_sum_beyond_max_grid(ctx, variant):
     # 2^30 + 3 elements: variants 3-5 would need 2^21 blocks; the grid is capped at 2^20, blocks must stride
     n = (1 << 30) + 3

@@ -52,7 +52,8 @@ def test_hello_runs_and_prices_are_sane(built):
     for label in ("Average CPU Vanilla Option", "Monte Carlo CPU Bullet Option Price", "Average GPU",
                   "Average GPU bullet option", "Average GPU bullet option atomic",
                   "Average GPU bullet option nmc one point per block", "Average GPU bullet option nmc one kernel",
-                  "Average GPU bullet option nmc optimal", "call Black Scholes"):
+                  "Average GPU bullet option nmc optimal", "call Black Scholes", "seeded CPU vanilla",
+                  "seeded CPU bullet"):
         m = re.search(re.escape(label) + r"\s*:\s*([-0-9.e+]+)", out.stdout)
         assert m, (label, out.stdout)
         vals[label] = float(m.group(1))
@@ -66,6 +67,14 @@ def test_hello_runs_and_prices_are_sane(built):
                                  "Average GPU bullet option nmc one kernel", "Average GPU bullet option nmc optimal"))
     assert a == b and abs(a - c) < 1e-3 * max(1.0, abs(a)) and a > 0
     assert "fp64 vanilla" in out.stdout
+    # the seeded CPU pricers are repeatable (mcamd_cpu_mc_f32 with std::mt19937(1234)), so GPU-vs-CPU agreement is a
+    # fixed-tolerance check: two independent 100 000-path estimates of the same price differ by N(0, 2 SE^2)
+    assert abs(vals["Average GPU"] - vals["seeded CPU vanilla"]) < 4 * math.sqrt(2) * se
+    se_bullet = 3.0 / math.sqrt(100000)     # bullet payoff: mostly zero, standard deviation ~3
+    assert abs(vals["Average GPU bullet option"] - vals["seeded CPU bullet"]) < 4 * math.sqrt(2) * se_bullet + 1e-3
+    again = subprocess.run([os.path.join(built, "hello")], capture_output=True, text=True, timeout=600)
+    m2 = re.search(r"seeded CPU bullet\s*:\s*([-0-9.e+]+)", again.stdout)
+    assert m2 and float(m2.group(1)) == vals["seeded CPU bullet"]          # same seed, same price
 
 
 @pytest.mark.gpu

@@ -60,19 +60,21 @@ extern "C" {
 #define MCAMD_NMC_BLOCK_PER_POINT 1 /* replaces compute_nmc_one_block_per_point, inc/nmc.cuh:12-108 */
 
 /* mcamd_sim.flags */
-#define MCAMD_FLAG_LOG_SPACE 1 /* carry ln(St/S0) through the step loop instead of St: one add per step instead of one
-                                  exp-and-multiply; every step still draws its normal and the price is exponentiated where
-                                  it is needed.  The same scheme (the exact GBM step, inc/trajectories.cuh:146) with the
-                                  product of the step factors re-associated into the exponential of their sum; rounding
-                                  differs at ~1e-14 relative in fp64.  This is how mcamd_price_paths runs a job WITHOUT a
-                                  barrier window by default (measured 12 % faster in fp64, 17 % in fp32, same oracle
-                                  tolerance); the flag asks for it where it is opt-in: window jobs of mcamd_price_paths and
-                                  mcamd_nmc_inner / _fused.  The store / array-driven kernels need St itself and ignore it. */
-#define MCAMD_FLAG_PRODUCT_FORM 16 /* mcamd_price_paths on a window-less job: carry the price itself, St *= exp(...) every
-                                  step — the reference's recurrence as written.  Keeps the in-register terminal price the
-                                  same BITS as the last row mcamd_simulate_trajectories stores for the same path (the store,
-                                  array-driven, window and nested-MC kernels always run this form unless LOG_SPACE is set).
-                                  Not combinable with MCAMD_FLAG_LOG_SPACE. */
+#define MCAMD_FLAG_LOG_SPACE 1 /* accepted for compatibility and redundant: it names what the in-register kernels do by
+                                  default (ABI <= 4 had it as an opt-in).  They carry ln(St/S0) through the step loop
+                                  instead of St — one add (window-less) or one fma and a compare (barrier window) per step
+                                  instead of an exponential and a multiply; every step still draws its normal, and the price
+                                  is exponentiated where it is needed.  The same scheme (the exact GBM step,
+                                  inc/trajectories.cuh:146) with the product of the step factors re-associated into the
+                                  exponential of their sum; rounding differs at ~1e-14 relative in fp64 (measured: 17 % /
+                                  21 % less time for window-less pricing in fp64 / fp32 with the pair sums of
+                                  csrc/mc_device.hpp, 12 % for the nested-MC inner stage; same oracle tolerances). */
+#define MCAMD_FLAG_PRODUCT_FORM 16 /* mcamd_price_paths, mcamd_nmc_inner, mcamd_nmc_fused: carry the price itself,
+                                  St *= exp(...) every step — the reference's recurrence as written — and test the barrier
+                                  on it.  Keeps the in-register terminal price the same BITS as the last row
+                                  mcamd_simulate_trajectories stores for the same path, and the barrier counts the same
+                                  integers as the stored ones.  (The store and array-driven kernels always run this form:
+                                  they need St at every step.)  Not combinable with MCAMD_FLAG_LOG_SPACE. */
 
 #define MCAMD_FLAG_ANTITHETIC 2 /* opt-in (mcamd_price_paths): a sample is the antithetic pair (G, -G) of one path's
                                   normals; its payoff is the pair's mean; n counts pairs.  New capability. */

@@ -137,21 +137,13 @@ mcamd::PathJob make_job(const mcamd_option *opt, const mcamd_sim *sim)
     j.path_offset = sim->path_offset;
     j.n_local = sim->n_paths_local;
     j.window = opt->use_window != 0;
-    j.logspace = (sim->flags & MCAMD_FLAG_LOG_SPACE) != 0;
+    // the in-register kernels (pricing with or without a window, nested-MC inner stage) carry ln(St / S0) unless the
+    // caller asks for the product form; the kernels that must produce St at every step ignore this
+    j.logspace = (sim->flags & MCAMD_FLAG_PRODUCT_FORM) == 0;
     j.vr = ((sim->flags & MCAMD_FLAG_ANTITHETIC) ? 1 : 0) | ((sim->flags & MCAMD_FLAG_CONTROL_VARIATE) ? 2 : 0);
     // E[S_T] under the simulated dynamics: S_start exp(r * remaining time)
     j.control_mean = j.S_start * std::exp(opt->r * dt * static_cast<double>(j.n_sim));
     j.precision = sim->precision;
-    return j;
-}
-
-// The job of mcamd_price_paths[_enqueue]: a window-less job sums the log-returns and exponentiates once
-// (MCAMD_FLAG_LOG_SPACE's form) unless the caller asks for the product form; window jobs keep the product form unless
-// the caller asks for log space.
-mcamd::PathJob make_pricing_job(const mcamd_option *opt, const mcamd_sim *sim)
-{
-    mcamd::PathJob j = make_job(opt, sim);
-    if (!j.window && !(sim->flags & MCAMD_FLAG_PRODUCT_FORM)) j.logspace = true;
     return j;
 }
 
@@ -548,7 +540,7 @@ int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *
     zero_result(res);
     if (sim->n_paths_local == 0) return MCAMD_OK;  // empty shard: all-zero statistics
     HIP_TRY(hipSetDevice(ctx->device));
-    const mcamd::PathJob job = make_pricing_job(opt, sim);
+    const mcamd::PathJob job = make_job(opt, sim);
     const int rec = (job.vr & 2) ? 5 : 2;
     const uint32_t grid = mcamd::price_grid(job, ctx->compute_units);
     if (int rc = ensure_partials(ctx, grid, rec)) return rc;
@@ -573,7 +565,7 @@ int mcamd_price_paths_enqueue(mcamd_ctx *ctx, const mcamd_option *opt, const mca
     if (!d_stats) return fail(MCAMD_ERR_INVALID, "d_stats is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     if (sim->n_paths_local == 0) return enqueue_empty(ctx, d_stats);
-    const mcamd::PathJob job = make_pricing_job(opt, sim);
+    const mcamd::PathJob job = make_job(opt, sim);
     const int rec = (job.vr & 2) ? 5 : 2;
     const uint32_t grid = mcamd::price_grid(job, ctx->compute_units);
     const Finish how = grid > mcamd::kFoldMaxRecords ? Finish::kReduce

@@ -171,7 +171,7 @@ __device__ __forceinline__ void box_muller(uint32_t x, uint32_t y, float &a, flo
 __device__ __forceinline__ void box_muller(const U4 &w, const MathCtx<double> &m, double &a, double &b)
 {
     const double u = f64::u53(w.x, w.y, 0x1p-53);   // (v1 + 1) 2^-53, exact
-    const double s = f64::sqrt_pos(f64::neg2log(u, m.t.log_tab));
+    const double s = f64::sqrt_unclamped(f64::neg2log(u, m.t.log_tab));   // -2 ln u > 0 for every u in (0, 1] (fast64.hpp)
     double sn, cs;
     f64::sincos_bits(w.z, w.w, m.t.sincos_tab, sn, cs);   // angle pi (v2 + 1) 2^-52, from the bits
     a = sn * s;
@@ -449,7 +449,7 @@ __device__ __forceinline__ double exp_of_logreturn(double S, double y, const Mat
 // inc/trajectories.cuh:144-148 (and the inner loops inc/nmc.cuh:55-59, :335-339).
 //
 // LOGSPACE = false: the reference's recurrence as written, St *= exp(drift + vol G) every step.
-// LOGSPACE = true (opt-in, MCAMD_FLAG_LOG_SPACE): the same scheme carried in the logarithm — every
+// LOGSPACE = true (the default of the in-register kernels): the same scheme carried in the logarithm — every
 // step still draws its normal, but the path accumulates ln(St / S_start) and exponentiates once at
 // the end; the barrier test B > St becomes ln(B / S_start) > ln(St / S_start).  Same mathematics,
 // different rounding (~1e-14 relative in fp64); one add (or add + fma + compare) per step instead
@@ -504,7 +504,7 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
     // lanes entering the next block with an open window (EARLY only; every active lane at the start)
     uint32_t open_lanes = EARLY ? static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(true))) : 0u;
     uint64_t live_steps = 0;   // up to 64 x n_sim
-    // LOGSPACE: WINDOW ? ln(St/S_start) so far : sum of the normals so far (the twin's sum is its negative)
+    // LOGSPACE: ln(St / S_ref) so far in exponent units (PAIRSUM: the sum of the normals so far / kUnit; the twin's is its negative)
     T acc = WINDOW ? log_start : T(0), acc2 = acc;
     static_assert(!PAIRSUM || (LOGSPACE && !WINDOW), "pair sums serve window-less log-space paths only");
     if constexpr (PAIRSUM) {
@@ -513,23 +513,23 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
         for (uint32_t k = 0; k < n_full; ++k) acc = PairSum<T>::add_block(acc, m, seed, subsequence, k);
         if (rem) acc += PairSum<T>::head(m, seed, subsequence, n_full, rem);
     } else if (LOGSPACE) {
-        Normals<T> nrm;
-        auto step = [&](T G) {
-            if (WINDOW) {
-                acc = fma_t(G, c.vol, acc + c.drift);
-                count += (c.logB > acc) ? 1 : 0;
-                if (ANTI) {
-                    acc2 = fma_t(-G, c.vol, acc2 + c.drift);
-                    count2 += (c.logB > acc2) ? 1 : 0;
-                }
-            } else {
-                acc += G;
+        // ln(St / S_ref) carried in the exponent's units: acc += x with x = drift + vol G the step's exponent (the
+        // same Exponents the product form multiplies by; the twin's is 2 drift - x).  The barrier test B > St is
+        // ln(B / S_start) > acc.
+        Exponents<T> ex;
+        const T two_drift = c.drift + c.drift;
+        auto step = [&](T x) {
+            acc += x;
+            if (WINDOW) count += (c.logB > acc) ? 1 : 0;
+            if (ANTI) {
+                acc2 += two_drift - x;
+                if (WINDOW) count2 += (c.logB > acc2) ? 1 : 0;
             }
         };
         for (uint32_t k = 0; k < n_full; ++k) {
-            nrm.fill(m, seed, subsequence, k);
+            ex.fill(m, c, seed, subsequence, k);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) step(nrm.z[j]);
+            for (int j = 0; j < NB; ++j) step(ex.x[j]);
             if (WINDOW && EARLY) {
                 live_steps += open_lanes * NB;
                 open_lanes = window_open_lanes<ANTI>(count, count2, c.P2);
@@ -541,10 +541,10 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
             }
         }
         if (rem && rem_live) {
-            nrm.fill(m, seed, subsequence, n_full);
+            ex.fill(m, c, seed, subsequence, n_full);
 #pragma unroll
             for (int j = 0; j < NB - 1; ++j)
-                if (static_cast<uint32_t>(j) < rem) step(nrm.z[j]);
+                if (static_cast<uint32_t>(j) < rem) step(ex.x[j]);
         }
     } else {
         // the reference's recurrence: St *= exp(drift + vol G); the twin uses drift - vol G = 2 drift - x.
@@ -585,17 +585,19 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
         St = ps.value(m);
         if (ANTI) St2 = ps2.value(m);
     }
-    if (LOGSPACE) {
+    if constexpr (PAIRSUM) {
+        // acc = (z_1 + ... + z_n) / kUnit: ln(S_T / S_in) = n drift + (vol kUnit) acc
         const T nd = c.drift * static_cast<T>(n_sim);
-        if (WINDOW) {
-            St = exp_of_logreturn(c.S_start, acc, m);
-            if (ANTI) St2 = exp_of_logreturn(c.S_start, acc2, m);
-        } else {
-            const T S_in = St;
-            const T vol_unit = PAIRSUM ? c.vol * PairSum<T>::kUnit : c.vol;   // pair sums count in units of kUnit
-            St = exp_of_logreturn(S_in, fma_t(acc, vol_unit, nd), m);
-            if (ANTI) St2 = exp_of_logreturn(S_in, fma_t(-acc, vol_unit, nd), m);
-        }
+        const T vol_unit = c.vol * PairSum<T>::kUnit;
+        const T S_in = St;
+        St = exp_of_logreturn(S_in, fma_t(acc, vol_unit, nd), m);
+        if (ANTI) St2 = exp_of_logreturn(S_in, fma_t(-acc, vol_unit, nd), m);
+    } else if (LOGSPACE) {
+        // acc = ln(St / S_ref) in exponent units; S_ref = c.S_start with a window (acc started at log_start), else the
+        // start price itself (acc started at 0)
+        const T S_ref = WINDOW ? c.S_start : St;
+        St = exp_of_logreturn(S_ref, acc, m);
+        if (ANTI) St2 = exp_of_logreturn(S_ref, acc2, m);
     }
     Sample<T> out;
     out.steps_run = steps_run;

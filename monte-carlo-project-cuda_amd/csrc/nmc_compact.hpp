@@ -123,8 +123,8 @@ __device__ __forceinline__ void wave_lds_fence()
 template <typename T, bool LOGSPACE>
 __device__ __forceinline__ void inner_step(const StepConsts<T> &c, const MathCtx<T> &m, InnerLane<T> &L, T x_or_z)
 {
-    if (LOGSPACE) {
-        L.acc = fma_t(x_or_z, c.vol, L.acc + c.drift);
+    if (LOGSPACE) {   // x = drift + vol G, the step's exponent: ln(St / S_start) grows by it
+        L.acc += x_or_z;
         L.count += (c.logB > L.acc) ? 1 : 0;
     } else {
         L.ps.step(x_or_z, m);
@@ -132,7 +132,8 @@ __device__ __forceinline__ void inner_step(const StepConsts<T> &c, const MathCtx
     }
 }
 
-// The draws of one Philox block of path L.j, as inner_step consumes them: exponents (product form) or normals.
+// The draws of one Philox block of a path, as inner_step consumes them: the steps' exponents x = drift + vol G, which
+// the product form multiplies the price by (e^x) and the log-space form adds up.
 template <typename T, bool LOGSPACE>
 struct BlockDraws {
     T v[Normals<T>::kPerBlock];
@@ -140,17 +141,10 @@ struct BlockDraws {
                                          uint64_t subsequence, uint32_t block)
     {
         constexpr int NB = Normals<T>::kPerBlock;
-        if (LOGSPACE) {
-            Normals<T> nrm;
-            nrm.fill(m, key, subsequence, block);
+        Exponents<T> ex;
+        ex.fill(m, c, key, subsequence, block);
 #pragma unroll
-            for (int s = 0; s < NB; ++s) v[s] = nrm.z[s];
-        } else {
-            Exponents<T> ex;
-            ex.fill(m, c, key, subsequence, block);
-#pragma unroll
-            for (int s = 0; s < NB; ++s) v[s] = ex.x[s];
-        }
+        for (int s = 0; s < NB; ++s) v[s] = ex.x[s];
     }
 };
 

@@ -1010,7 +1010,12 @@ def test_full_size_config4_properties(ctx):
     out = dev(n_paths * n_steps, torch.float64)
     res = ctx.nmc_inner(opt, capi.make_sim(n_paths, n_steps, capi.F64, seed=1235, n_paths_inner=n_inner), traj, cnt, out)
     V, S = out.view(n_steps, n_paths), traj.view(n_steps, n_paths)
-    assert torch.allclose(V[-1], torch.clamp(S[-1] - 100.0, min=0.0) * math.exp(-0.1), rtol=1e-13, atol=0)
+    # (the inner paths carry ln(St / S0): a stored price goes through log and exp once, 1e-16 of St, i.e. of ~100)
+    assert torch.allclose(V[-1], torch.clamp(S[-1] - 100.0, min=0.0) * math.exp(-0.1), rtol=1e-13, atol=1e-12)
+    prod = dev(n_paths, torch.float64)
+    last_only = capi.make_sim(n_paths, 1, capi.F64, seed=1235, n_paths_inner=8, flags=capi.FLAG_PRODUCT_FORM)
+    ctx.nmc_inner(opt, last_only, S[-1].contiguous(), cnt.view(n_steps, n_paths)[-1].contiguous(), prod)
+    assert torch.allclose(prod, torch.clamp(S[-1] - 100.0, min=0.0) * math.exp(-0.1), rtol=1e-13, atol=0)   # product form: St itself
     assert torch.isfinite(out).all() and (out >= 0).all() and res.n == n_paths * n_steps
     se_outer = 16.109 / math.sqrt(n_paths)
     for s_ in (0, 50, 125, 200, 251):

@@ -162,9 +162,12 @@ KERNELS = {
     # nested MC inner stage, fp64, barrier window (BASELINE configs[3]): St is evaluated at every step for the count
     # two step loops since the lane compaction (csrc/nmc_compact.hpp): batches of fresh paths (block index uniform) and
     # batches of resumed ones (block index per lane: the first Philox round loses its scalar half)
-    "nmc_wave_f64_window": ("nmc.hip", "_ZN5mcamd15nmc_wave_kernelIdLb1ELi0ELb0EEE", 2, "fewest_mul"),
-    "nmc_wave_f64_window_resumed": ("nmc.hip", "_ZN5mcamd15nmc_wave_kernelIdLb1ELi0ELb0EEE", 2, "most_mul"),
-    "price_f64_window": ("price_f64.hip", "_ZN5mcamd12price_kernelIdLb1ELb0ELi0EEE", 2),
+    # (the default loops carry ln(St/S0): LOGSPACE = true; *_product = MCAMD_FLAG_PRODUCT_FORM)
+    "nmc_wave_f64_window": ("nmc.hip", "_ZN5mcamd15nmc_wave_kernelIdLb1ELi0ELb1EEE", 2, "fewest_mul"),
+    "nmc_wave_f64_window_resumed": ("nmc.hip", "_ZN5mcamd15nmc_wave_kernelIdLb1ELi0ELb1EEE", 2, "most_mul"),
+    "nmc_wave_f64_window_product": ("nmc.hip", "_ZN5mcamd15nmc_wave_kernelIdLb1ELi0ELb0EEE", 2, "fewest_mul"),
+    "price_f64_window": ("price_f64.hip", "_ZN5mcamd12price_kernelIdLb1ELb1ELi0EEE", 2),
+    "price_f64_window_product": ("price_f64.hip", "_ZN5mcamd12price_kernelIdLb1ELb0ELi0EEE", 2),
 }
 
 

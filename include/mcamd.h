@@ -57,7 +57,11 @@ extern "C" {
  * the fused single launch, is mcamd_nmc_fused and equals WAVE_PER_POINT bit for bit) */
 #define MCAMD_NMC_WAVE_PER_POINT 0  /* replaces compute_nmc_optimal, inc/nmc.cuh:280-386.  The fast one: with a window,
                                        wavefronts refill lanes whose path is over instead of waiting for the last */
-#define MCAMD_NMC_BLOCK_PER_POINT 1 /* replaces compute_nmc_one_block_per_point, inc/nmc.cuh:12-108 */
+#define MCAMD_NMC_BLOCK_PER_POINT 1 /* replaces compute_nmc_one_block_per_point, inc/nmc.cuh:12-108: one workgroup per point;
+                                       with a window each of its wavefronts compacts its share of the point's paths */
+#define MCAMD_NMC_BLOCK_PER_POINT_PLAIN 2 /* the same without lane compaction (path j on thread j mod 256, a wavefront waits
+                                       for its last lane): the independent implementation the compacting kernels are
+                                       fuzzed against (tools/fuzz_nmc.py); 2-3x slower with the reference's window */
 
 /* mcamd_sim.flags */
 #define MCAMD_FLAG_LOG_SPACE 1 /* accepted for compatibility and redundant: it names what the in-register kernels do by

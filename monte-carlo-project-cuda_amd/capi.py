@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG, "libmcamd.so")
 OK, ERR_INVALID, ERR_HIP, ERR_NODEVICE, ERR_NOMEM = 0, 1, 2, 3, 4
 F32, F64 = 32, 64
 STEP_MAJOR, PATH_MAJOR = 0, 1
-NMC_WAVE_PER_POINT, NMC_BLOCK_PER_POINT = 0, 1
+NMC_WAVE_PER_POINT, NMC_BLOCK_PER_POINT, NMC_BLOCK_PER_POINT_PLAIN = 0, 1, 2
 FLAG_LOG_SPACE, FLAG_ANTITHETIC, FLAG_CONTROL_VARIATE, FLAG_SEPARATE_REDUCE, FLAG_PRODUCT_FORM = 1, 2, 4, 8, 16
 REDUCE_SEQUENTIAL, REDUCE_FIRST_ADD, REDUCE_UNROLL_LAST, REDUCE_GRID_STRIDE = 3, 4, 5, 6
 

@@ -291,7 +291,8 @@ int prepare_nmc(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, i
         return fail(MCAMD_ERR_INVALID, "variance-reduction flags apply to mcamd_price_paths only");
     if (layout != MCAMD_STEP_MAJOR && layout != MCAMD_PATH_MAJOR)
         return fail(MCAMD_ERR_INVALID, "layout must be MCAMD_STEP_MAJOR or MCAMD_PATH_MAJOR");
-    if (!fused && variant != MCAMD_NMC_WAVE_PER_POINT && variant != MCAMD_NMC_BLOCK_PER_POINT)
+    if (!fused && variant != MCAMD_NMC_WAVE_PER_POINT && variant != MCAMD_NMC_BLOCK_PER_POINT &&
+        variant != MCAMD_NMC_BLOCK_PER_POINT_PLAIN)
         return fail(MCAMD_ERR_INVALID, "unknown nested-MC variant %d", variant);
     if (opt->Tk != 0) return fail(MCAMD_ERR_INVALID, "nested MC expects outer trajectories stored from step 0 (Tk = 0)");
     if (fused && outer_seed == sim->seed)

@@ -192,12 +192,27 @@ __global__ __launch_bounds__(kBlock) void nmc_wave_kernel(NmcArgs<T> a, double *
     }
 }
 
-template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE>
+// One WORKGROUP per point (compute_nmc_one_block_per_point, inc/nmc.cuh:12-108).  COMPACT (the default with a window):
+// each of the workgroup's four wavefronts takes a quarter of the point's continuation paths (a multiple of 64) and runs
+// them as a compaction pool of its own (nmc_compact.hpp), so a wavefront refills its lanes as paths leave the window
+// instead of waiting for its slowest lane; the pool is the point's alone, so a point's price does not depend on which
+// other points are priced beside it.  !COMPACT (MCAMD_NMC_BLOCK_PER_POINT_PLAIN): path j goes to thread j mod 256 and
+// every wavefront waits for its last lane — no shared machinery with the compacting kernels, which is why the
+// differential fuzzers (tools/fuzz_nmc.py) keep it as their reference.
+template <typename T, bool WINDOW, int LAYOUT, bool LOGSPACE, bool COMPACT>
 __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double *__restrict__ partials)
 {
+    constexpr int kWaves = kBlock / kWave;
     const MathCtx<T> m = MathCtx<T>::init();
     const PhiloxKeys key = PhiloxKeys::make(a.seed);
     const StepConsts<T> c = resident(a.c);
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = threadIdx.x / kWave;
+    __shared__ ParkedPaths<T, WINDOW && COMPACT> s_parked[kWaves];
+    // this wavefront's share of a point's continuation paths: [j_lo, j_hi), whole wavefront-loads except the last
+    const uint32_t share = ((a.n_inner + kWaves - 1) / kWaves + kWave - 1) / kWave * kWave;
+    const uint32_t j_lo = wave * share < a.n_inner ? wave * share : a.n_inner;
+    const uint32_t j_hi = j_lo + share < a.n_inner ? j_lo + share : a.n_inner;
     double psum = 0.0, psumsq = 0.0, pwork = 0.0, plive = 0.0;
     for (uint64_t task = blockIdx.x; task < a.n_points; task += gridDim.x) {
         uint32_t step;
@@ -209,14 +224,33 @@ __global__ __launch_bounds__(kBlock) void nmc_block_kernel(NmcArgs<T> a, double 
         const uint64_t point_id = (a.path_offset + path) * a.n_steps + step;
         double acc = 0.0;
         uint64_t steps_run = 0, live_steps = 0;   // 64-bit: a point may hold more than 2^32 lane-steps
-        if (!WINDOW || cnt0 <= c.P2) {
-            const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
-            for (uint32_t j = threadIdx.x; j < a.n_inner; j += kBlock)
-                acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(
-                    c, m, key, point_id * a.n_inner + j, St0, cnt0, remaining, ls, &steps_run, &live_steps));
+        if constexpr (WINDOW && COMPACT) {
+            ParkedPaths<T, true> &buf = s_parked[wave];
+            if (lane < kPool) {   // slot 0: this wavefront's share of the point; the other slots stay empty
+                const bool mine = lane == 0 && j_hi > j_lo && cnt0 <= c.P2;
+                buf.pt_St0[lane] = St0;
+                buf.pt_cnt0[lane] = mine ? cnt0 : kNoPath;
+                buf.pt_log_start[lane] = (mine && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
+                buf.pt_subsequence[lane] = point_id * a.n_inner + j_lo;
+                buf.pt_n[lane] = j_hi - j_lo;
+                buf.pt_sum[lane] = 0.0;
+                buf.pt_sumsq[lane] = 0.0;
+            }
+            wave_lds_fence();
+            group_sums_compacted<T, LOGSPACE>(c, m, key, remaining, buf, steps_run, live_steps);
+            wave_lds_fence();
+            acc = lane == 0 ? buf.pt_sum[0] : 0.0;
+            wave_lds_fence();   // the next point's description must not overtake this read
+        } else {
+            if (!WINDOW || cnt0 <= c.P2) {
+                const T ls = (WINDOW && (LOGSPACE || sizeof(T) == 8)) ? log_ratio(St0, c.S_start) : T(0);
+                for (uint32_t j = threadIdx.x; j < a.n_inner; j += kBlock)
+                    acc += static_cast<double>(simulate_path<T, WINDOW, LOGSPACE>(
+                        c, m, key, point_id * a.n_inner + j, St0, cnt0, remaining, ls, &steps_run, &live_steps));
+            }
         }
         // wave-steps and live lane-steps: each wavefront's first lane runs every pass that wavefront makes
-        const bool first_lane = (threadIdx.x & (kWave - 1)) == 0;
+        const bool first_lane = lane == 0;
         double pt[3] = {acc, first_lane ? static_cast<double>(steps_run) : 0.0,
                         first_lane ? static_cast<double>(WINDOW ? live_steps : 0ull) : 0.0};
         block_sumN<kBlock, 3>(pt);
@@ -376,7 +410,7 @@ static void launch_fused_variant(const NmcArgs<T> &a, uint64_t outer_seed, bool 
 
 uint32_t nmc_grid(const NmcJob &job, int variant)
 {
-    if (variant == MCAMD_NMC_BLOCK_PER_POINT) return clamp_grid(job.n_points);
+    if (variant == MCAMD_NMC_BLOCK_PER_POINT || variant == MCAMD_NMC_BLOCK_PER_POINT_PLAIN) return clamp_grid(job.n_points);
     // wave per point: persistent grid, 8 workgroups per CU (all that can be resident), tasks pulled from a queue
     const uint64_t groups = (job.path.path_offset % kPool + job.path.n_local + kPool - 1) / kPool * job.path.n_steps;   // the kernel's tasks
     const uint64_t per_block = static_cast<uint64_t>(kBlock / kWave);
@@ -391,8 +425,11 @@ static void launch_variant(const NmcArgs<T> &a, int variant, bool logspace, doub
 {
     const dim3 g(grid), b(kBlock);
     if (variant == MCAMD_NMC_BLOCK_PER_POINT) {
-        if (logspace) hipLaunchKernelGGL((nmc_block_kernel<T, WINDOW, LAYOUT, true>), g, b, 0, stream, a, d_partials);
-        else hipLaunchKernelGGL((nmc_block_kernel<T, WINDOW, LAYOUT, false>), g, b, 0, stream, a, d_partials);
+        if (logspace) hipLaunchKernelGGL((nmc_block_kernel<T, WINDOW, LAYOUT, true, true>), g, b, 0, stream, a, d_partials);
+        else hipLaunchKernelGGL((nmc_block_kernel<T, WINDOW, LAYOUT, false, true>), g, b, 0, stream, a, d_partials);
+    } else if (variant == MCAMD_NMC_BLOCK_PER_POINT_PLAIN) {
+        if (logspace) hipLaunchKernelGGL((nmc_block_kernel<T, WINDOW, LAYOUT, true, false>), g, b, 0, stream, a, d_partials);
+        else hipLaunchKernelGGL((nmc_block_kernel<T, WINDOW, LAYOUT, false, false>), g, b, 0, stream, a, d_partials);
     } else {
         if (logspace)
             hipLaunchKernelGGL((nmc_wave_kernel<T, WINDOW, LAYOUT, true>), g, b, 0, stream, a, d_partials, d_queue);

@@ -256,7 +256,7 @@ def test_in_kernel_finish_equals_the_separate_reduction_bit_for_bit(ctx):
             (plain, 100_003, 30, capi.F64, 0), (plain, 1_000_000, 20, capi.F32, 0), (plain, 2_097_152, 8, capi.F64, 0),
             (plain, 300_000, 16, capi.F64, vr), (plain, 77_777, 9, capi.F32, capi.FLAG_CONTROL_VARIATE),
             (bullet, 200_001, 60, capi.F64, 0), (bullet, 4_000_000, 64, capi.F32, 0),
-            (plain, 50_000, 40, capi.F64, capi.FLAG_LOG_SPACE)]
+            (plain, 50_000, 40, capi.F64, capi.FLAG_PRODUCT_FORM), (bullet, 60_000, 40, capi.F32, capi.FLAG_PRODUCT_FORM)]
     noise_stream = torch.cuda.Stream()
     x = torch.randn(1 << 26, device="cuda")
     stats = torch.zeros(2, 8, dtype=torch.float64, device="cuda")
@@ -445,17 +445,20 @@ def test_price_other_options_within_se(ctx, S0, K, T, r, v):
     assert abs(res.price - capi.bs_call_f64(S0, K, T, r, v)) <= 4 * res.std_err
 
 
-# ---------------- opt-in log-space stepping ----------------
+# ---------------- the two forms of the step loop: ln(St/S0) carried (default) and the product form (opt-in) ----------------
 @pytest.mark.parametrize("prec", [capi.F32, capi.F64])
 @pytest.mark.parametrize("window", [0, 1])
 @pytest.mark.parametrize("n_paths,n_steps", [(1, 1), (1000, 3), (20_000, 100), (5000, 253)])
 def test_log_space_mode_vs_oracle(ctx, oracle, prec, window, n_paths, n_steps):
-    # MCAMD_FLAG_LOG_SPACE carries ln(St/S0) instead of St: same draws, same scheme, rounding differs
+    # the in-register kernels carry ln(St/S0) instead of St by default (MCAMD_FLAG_LOG_SPACE names it, redundantly);
+    # MCAMD_FLAG_PRODUCT_FORM is the reference's recurrence: same draws, same scheme, rounding differs — both against
+    # the oracle, which restates the product recurrence
     opt = capi.make_option(**BENCH, B=120.0, P1=10 if n_steps >= 100 else 0, P2=50 if n_steps >= 100 else n_steps,
                            use_window=window)
     sim = capi.make_sim(n_paths, n_steps, prec, seed=77, flags=capi.FLAG_LOG_SPACE)
     res = ctx.price_paths(opt, sim)
-    plain = ctx.price_paths(opt, capi.make_sim(n_paths, n_steps, prec, seed=77))
+    assert res.sum == ctx.price_paths(opt, capi.make_sim(n_paths, n_steps, prec, seed=77)).sum
+    plain = ctx.price_paths(opt, capi.make_sim(n_paths, n_steps, prec, seed=77, flags=capi.FLAG_PRODUCT_FORM))
     ref = oracle.mc_paths(oparams(oracle, opt, sim), prec, 0, n_paths, threads=oracle.max_threads())
     tol = 1e-11 if prec == capi.F64 else (2e-3 if window else 5e-5)
     assert math.isclose(res.sum, ref["sum"], rel_tol=tol, abs_tol=1e-6)
@@ -490,19 +493,20 @@ def test_log_space_nmc_matches_plain(ctx):
     a, b = dev(n_paths * n_steps, torch.float64), dev(n_paths * n_steps, torch.float64)
     ctx.nmc_inner(opt, capi.make_sim(n_paths, n_steps, capi.F64, seed=1235, n_paths_inner=n_inner), traj, cnt, a)
     ctx.nmc_inner(opt, capi.make_sim(n_paths, n_steps, capi.F64, seed=1235, n_paths_inner=n_inner,
-                                     flags=capi.FLAG_LOG_SPACE), traj, cnt, b)
-    assert torch.allclose(a, b, rtol=1e-11, atol=1e-12)
+                                     flags=capi.FLAG_PRODUCT_FORM), traj, cnt, b)
+    assert torch.allclose(a, b, rtol=1e-11, atol=1e-12) and not torch.equal(a, b)
 
 
 @pytest.mark.parametrize("prec", [capi.F32, capi.F64])
-@pytest.mark.parametrize("flags", [0, capi.FLAG_LOG_SPACE])
+@pytest.mark.parametrize("flags", [0, capi.FLAG_PRODUCT_FORM])
 def test_nmc_lane_compaction_is_invisible_in_the_results(ctx, oracle, prec, flags):
     # The wave-per-point kernel parks a wavefront's last live continuation paths in LDS and resumes them 64 at a time
     # (csrc/nmc_compact.hpp).  A window that closes for most paths after a few steps while some run to maturity makes
     # every mechanism fire (hand-over, resume of a full wavefront, drain of the rest); 1000 and 77 inner paths cover a
-    # partial last round.  Every point must still equal the oracle's per-path loop and the block-per-point kernel
+    # partial last round.  Every point must still equal the oracle's per-path loop and the PLAIN block-per-point kernel
     # (which does not compact), the fused kernel must equal the two-launch route bit for bit, a repeat must be
-    # bit-identical, and the executed work must be below the uncompacted kernel's.
+    # bit-identical, and the executed work must be below the uncompacted kernel's — for the wave-per-point kernel and for
+    # the block-per-point kernel, whose wavefronts each compact their share of a point's paths.
     n_paths, n_steps = 24, 61      # odd remaining-step counts exercise the partial last Philox block
     opt = capi.make_option(**BENCH, B=104.0, P1=2, P2=9, use_window=1)
     outer = capi.make_sim(n_paths, n_steps, prec, seed=4242)
@@ -510,18 +514,21 @@ def test_nmc_lane_compaction_is_invisible_in_the_results(ctx, oracle, prec, flag
     ctx.simulate_trajectories(opt, outer, traj, cnt)
     for n_inner in (1000, 77):
         inner = capi.make_sim(n_paths, n_steps, prec, seed=99, n_paths_inner=n_inner, flags=flags)
-        w, w2, b, f = (dev(n_paths * n_steps, TORCH_T[prec]) for _ in range(4))
+        w, w2, b, f, bc, bc2 = (dev(n_paths * n_steps, TORCH_T[prec]) for _ in range(6))
         rw = ctx.nmc_inner(opt, inner, traj, cnt, w, capi.STEP_MAJOR, capi.NMC_WAVE_PER_POINT)
         ctx.nmc_inner(opt, inner, traj, cnt, w2, capi.STEP_MAJOR, capi.NMC_WAVE_PER_POINT)
-        rb = ctx.nmc_inner(opt, inner, traj, cnt, b, capi.STEP_MAJOR, capi.NMC_BLOCK_PER_POINT)
+        rb = ctx.nmc_inner(opt, inner, traj, cnt, b, capi.STEP_MAJOR, capi.NMC_BLOCK_PER_POINT_PLAIN)
+        rc = ctx.nmc_inner(opt, inner, traj, cnt, bc, capi.STEP_MAJOR, capi.NMC_BLOCK_PER_POINT)
+        ctx.nmc_inner(opt, inner, traj, cnt, bc2, capi.STEP_MAJOR, capi.NMC_BLOCK_PER_POINT)
         t2, c2 = torch.empty_like(traj), torch.empty_like(cnt)
         ctx.nmc_fused(opt, inner, 4242, t2, c2, f)
         assert torch.equal(w, w2) and torch.equal(f, w) and torch.equal(t2, traj) and torch.equal(c2, cnt)
         tol = dict(rtol=1e-11, atol=1e-12) if prec == capi.F64 else dict(rtol=2e-4, atol=2e-4)
-        assert torch.allclose(w, b, **tol)
-        assert 0 < rw.live_steps <= rw.work_steps and 0 < rb.live_steps <= rb.work_steps
+        assert torch.allclose(w, b, **tol) and torch.allclose(bc, b, **tol) and torch.equal(bc, bc2)
+        assert 0 < rw.live_steps <= rw.work_steps and 0 < rb.live_steps <= rb.work_steps and 0 < rc.live_steps <= rc.work_steps
         if n_inner == 1000:
-            assert 0 < rw.work_steps < 0.8 * rb.work_steps
+            assert 0 < rw.work_steps < 0.8 * rb.work_steps and rc.work_steps < 0.9 * rb.work_steps
+            assert abs(rc.live_steps - rb.live_steps) < 0.02 * rb.live_steps
             # both kernels count the same live paths (to within the block in which a path's window closes); the
             # compacting kernel spends far fewer lane-steps on them
             assert abs(rw.live_steps - rb.live_steps) < 0.02 * rb.live_steps
@@ -713,7 +720,7 @@ def test_reduce_misaligned_input(ctx):
 
 # ---------------- nested Monte Carlo ----------------
 @pytest.mark.parametrize("prec", [capi.F32, capi.F64])
-@pytest.mark.parametrize("variant", [capi.NMC_WAVE_PER_POINT, capi.NMC_BLOCK_PER_POINT])
+@pytest.mark.parametrize("variant", [capi.NMC_WAVE_PER_POINT, capi.NMC_BLOCK_PER_POINT, capi.NMC_BLOCK_PER_POINT_PLAIN])
 @pytest.mark.parametrize("layout", [capi.STEP_MAJOR, capi.PATH_MAJOR])
 def test_nmc_inner_vs_oracle_bruteforce(ctx, oracle, prec, variant, layout):
     n_paths, n_steps, n_inner = 6, 9, 100
@@ -863,7 +870,7 @@ def test_nmc_inner_ragged_inner_counts(ctx, oracle, n_inner):
     T_, C_ = traj.view(n_steps, n_paths).cpu().numpy(), cnt.view(n_steps, n_paths).cpu().numpy()
     want = np.array([[oracle.nmc_point(p, 64, q * n_steps + s_, s_, float(T_[s_, q]), int(C_[s_, q]))
                       for q in range(n_paths)] for s_ in range(n_steps)])
-    for variant in (capi.NMC_WAVE_PER_POINT, capi.NMC_BLOCK_PER_POINT):
+    for variant in (capi.NMC_WAVE_PER_POINT, capi.NMC_BLOCK_PER_POINT, capi.NMC_BLOCK_PER_POINT_PLAIN):
         out = dev(n_paths * n_steps, torch.float64)
         ctx.nmc_inner(opt, inner, traj, cnt, out, capi.STEP_MAJOR, variant)
         assert np.allclose(out.view(n_steps, n_paths).cpu().numpy(), want, rtol=1e-11, atol=1e-12), variant
@@ -921,7 +928,8 @@ def test_randomised_jobs_vs_oracle(ctx, oracle):
         Tk = int(rng.integers(0, n_steps)) if (window and rng.random() < 0.3) else 0
         Ik = int(rng.integers(0, 5)) if Tk else 0
         Sk = S0 * float(rng.uniform(0.8, 1.2)) if Tk else 0.0
-        flags = int(rng.choice([0, 0, 0, capi.FLAG_LOG_SPACE, capi.FLAG_ANTITHETIC]))
+        flags = int(rng.choice([0, 0, capi.FLAG_PRODUCT_FORM, capi.FLAG_PRODUCT_FORM, capi.FLAG_ANTITHETIC,
+                                capi.FLAG_ANTITHETIC | capi.FLAG_PRODUCT_FORM]))
         dt = float(T / n_steps * rng.uniform(0.5, 1.5)) if (n_steps > 1 and rng.random() < 0.2) else 0.0
         opt = capi.make_option(S0, T, K, r, v, B=B, P1=P1, P2=P2, use_window=window, Ik=Ik, Sk=Sk, Tk=Tk, dt=dt)
         sim = capi.make_sim(n_paths, n_steps, prec, seed=int(rng.integers(1, 1 << 40)),
@@ -1044,7 +1052,7 @@ def test_option_dt_is_honoured_like_optiondata_step(ctx, oracle):
 
 
 @pytest.mark.parametrize("prec", [capi.F32, capi.F64])
-@pytest.mark.parametrize("flags", [0, capi.FLAG_LOG_SPACE, capi.FLAG_ANTITHETIC])
+@pytest.mark.parametrize("flags", [0, capi.FLAG_PRODUCT_FORM, capi.FLAG_ANTITHETIC, capi.FLAG_ANTITHETIC | capi.FLAG_PRODUCT_FORM])
 def test_closed_window_early_exit_changes_nothing(ctx, oracle, prec, flags):
     # B = 120 > S0: nearly every step counts, P2 = 50 of 252 steps: the window closes for whole wavefronts long before
     # maturity and they leave the step loop (mc_device.hpp simulate_sample).  The sums must equal the oracle's, which
@@ -1081,7 +1089,7 @@ def test_barrier_test_band_scales_with_path_length(ctx, oracle, n_paths, n_steps
 
 
 @pytest.mark.parametrize("prec", [capi.F32, capi.F64])
-@pytest.mark.parametrize("flags", [0, capi.FLAG_LOG_SPACE])
+@pytest.mark.parametrize("flags", [0, capi.FLAG_PRODUCT_FORM])
 def test_bullet_pricing_of_many_paths_compacts_and_changes_nothing(ctx, oracle, prec, flags):
     # mcamd_price_paths with a window over >= 3.1M paths runs the lane-compacting kernel (csrc/price_impl.hpp:
     # price_window_compact_kernel); below that, one path per thread.  The same job priced whole (compacting) and as

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the nested-MC strategies on the GPU (no oracle: the block-per-point kernel, which does not
-compact lanes, is the reference for the compacting wave-per-point and fused kernels).  Runs for --seconds.
+"""Differential fuzz of the nested-MC strategies on the GPU (no oracle: the PLAIN block-per-point kernel, which does
+not compact lanes, is the reference for the compacting wave-per-point, block-per-point and fused kernels).  Runs for --seconds.
     python3 tools/fuzz_nmc.py --seconds 120 --seed 1
 Prints one JSON line: cases run, worst relative deviation, failures (empty when all agree)."""
 import argparse
@@ -38,7 +38,7 @@ def main():
         B = 100.0 * float(rng.choice([0.0, 0.85, 0.97, 1.0, 1.03, 1.1, 1.3, 3.0]))
         P1 = int(rng.integers(0, n_steps + 1))
         P2 = int(rng.integers(P1, n_steps + 2)) if rng.random() < 0.9 else 2**31 - 1
-        flags = capi.FLAG_LOG_SPACE if rng.random() < 0.3 else 0
+        flags = capi.FLAG_PRODUCT_FORM if rng.random() < 0.4 else 0   # the reference's recurrence, or the default (log space)
         layout = capi.STEP_MAJOR if rng.random() < 0.5 else capi.PATH_MAJOR
         v = float(rng.choice([0.05, 0.2, 0.6]))
         opt = capi.make_option(100.0, 1.0, 100.0, 0.1, v, B=B, P1=P1, P2=P2, use_window=1)
@@ -54,16 +54,18 @@ def main():
         n = n_paths * n_steps
         traj = torch.empty(n, dtype=tt[prec], device="cuda")
         cnt = torch.empty(n, dtype=torch.int32, device="cuda")
-        w, b, f = (torch.empty(n, dtype=tt[prec], device="cuda") for _ in range(3))
+        w, b, f, bc = (torch.empty(n, dtype=tt[prec], device="cuda") for _ in range(4))
         ctx.simulate_trajectories(opt, outer, traj, cnt, None, layout)
         rw = ctx.nmc_inner(opt, inner, traj, cnt, w, layout, capi.NMC_WAVE_PER_POINT)
-        rb = ctx.nmc_inner(opt, inner, traj, cnt, b, layout, capi.NMC_BLOCK_PER_POINT)
+        rb = ctx.nmc_inner(opt, inner, traj, cnt, b, layout, capi.NMC_BLOCK_PER_POINT_PLAIN)
+        ctx.nmc_inner(opt, inner, traj, cnt, bc, layout, capi.NMC_BLOCK_PER_POINT)
         t2, c2 = torch.empty_like(traj), torch.empty_like(cnt)
         ctx.nmc_fused(opt, inner, so, t2, c2, f, layout)
         tol = (1e-11, 1e-11) if prec == capi.F64 else (3e-4, 3e-4)
         dev = float(((w - b).abs() / (b.abs() + (1e-3 if prec == capi.F32 else 1e-9))).max().item())
         worst = max(worst, dev) if prec == capi.F64 else worst
-        ok = (torch.allclose(w, b, rtol=tol[0], atol=tol[1]) and torch.equal(w, f) and torch.equal(t2, traj)
+        ok = (torch.allclose(w, b, rtol=tol[0], atol=tol[1]) and torch.allclose(bc, b, rtol=tol[0], atol=tol[1])
+              and torch.equal(w, f) and torch.equal(t2, traj)
               and torch.equal(c2, cnt) and rw.live_steps <= rw.work_steps and bool(torch.isfinite(w).all()))
         # the two kernels count a path's last, window-closing block differently at most
         ok = ok and abs(rw.live_steps - rb.live_steps) <= 0.25 * max(rb.live_steps, 1.0) + 64 * 4

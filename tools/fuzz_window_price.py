@@ -41,7 +41,7 @@ def main():
         B = 100.0 * float(rng.choice([0.0, 0.9, 1.0, 1.05, 1.2, 3.0]))
         P1 = int(rng.integers(0, max(1, n_steps // 2)))
         P2 = int(rng.integers(P1, n_steps + 2)) if rng.random() < 0.9 else 2**31 - 1
-        flags = capi.FLAG_LOG_SPACE if rng.random() < 0.3 else 0
+        flags = capi.FLAG_PRODUCT_FORM if rng.random() < 0.4 else 0   # the reference's recurrence, or the default (log space)
         v = float(rng.choice([0.05, 0.2, 0.6]))
         opt = capi.make_option(100.0, 1.0, 100.0, 0.1, v, B=B, P1=P1, P2=P2, use_window=1, Ik=Ik, Sk=Sk, Tk=Tk)
         seed = int(rng.integers(1, 1 << 31))

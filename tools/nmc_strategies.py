@@ -28,7 +28,8 @@ def main():
     out = torch.empty(n_paths * n_steps, dtype=torch.float64, device="cuda")
     ro = ctx.simulate_trajectories(opt, outer, traj, cnt)
     res = {"outer_kernel_ms": ro.kernel_ms}
-    for name, variant in (("wave", capi.NMC_WAVE_PER_POINT), ("block", capi.NMC_BLOCK_PER_POINT)):
+    for name, variant in (("wave", capi.NMC_WAVE_PER_POINT), ("block", capi.NMC_BLOCK_PER_POINT),
+                          ("block_plain", capi.NMC_BLOCK_PER_POINT_PLAIN)):
         r = ctx.nmc_inner(opt, inner, traj, cnt, out, variant=variant)
         res[name] = {"kernel_ms": r.kernel_ms, "work_steps": r.work_steps, "live_steps": r.live_steps,
                      "lane_efficiency": r.live_steps / r.work_steps, "mean_point_price": r.price,

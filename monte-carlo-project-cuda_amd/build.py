@@ -56,8 +56,8 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src: str, force: bool, extra) -> str:
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+def _compile(src: str, force: bool, extra, obj_dir: str = OBJ) -> str:
+    obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [
         os.path.join(ROOT, "include", "mcamd.h"), os.path.abspath(__file__)]
     if src == "capi.cpp":   # carries the build id, a hash over EVERY source
@@ -80,6 +80,21 @@ def build(force: bool = False, extra_flags=(), jobs: int = 6) -> str:
         subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", LIB, "-ldl"])
     refresh_slot_counts(tuple(extra_flags))
     return LIB
+
+
+def build_variant(tag: str, extra_flags, jobs: int = 6) -> str:
+    """A second library beside the shipped one, built from the same sources with extra -D flags:
+    monte-carlo-project-cuda_amd/libmcamd_<tag>.so (objects under csrc/build/<tag>/).  For same-box A/B measurements of
+    a source-level variant (tools/ab_lib.py loads it through MCAMD_LIB); never loaded by the package itself, and its
+    mcamd_build_id differs from the shipped library's because the flags are part of the id."""
+    obj_dir = os.path.join(OBJ, tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    lib = os.path.join(PKG, f"libmcamd_{tag}.so")
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile(s, False, tuple(extra_flags), obj_dir), SOURCES))
+    if _stale(lib, objs):
+        subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", lib, "-ldl"])
+    return lib
 
 
 def refresh_slot_counts(extra=()) -> bool:

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libmcamd.so")
+# MCAMD_LIB: diagnostic override for same-box A/B runs of a variant build (build.build_variant, tools/ab_lib.py)
+LIB_PATH = os.environ.get("MCAMD_LIB") or os.path.join(PKG, "libmcamd.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NODEVICE, ERR_NOMEM = 0, 1, 2, 3, 4
 F32, F64 = 32, 64

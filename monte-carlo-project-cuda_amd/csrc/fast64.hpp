@@ -47,6 +47,21 @@ struct Tables {
     const double *exp_lo_tab; // 2^(i/65536), i in [0, 256)
 };
 
+// One 16-byte table entry {a, b}.  Experiment (-DMCAMD_LDS_PLANES, profiles/r03_lds_planes_ab.txt): the same table as
+// two 8-byte planes, a[0..N) then b[0..N), read with two ds_read_b64 instead of one ds_read_b128 — VERDICT r02 asked
+// whether that lowers the LDS bank conflicts of the random lookups enough to show in the time.  Not the shipped layout.
+MC_HD D2 table_entry(const D2 *tab, uint32_t byte_offset_of_entry)
+{
+#if defined(MCAMD_LDS_PLANES)
+    const char *base = reinterpret_cast<const char *>(tab);
+    const uint32_t half = byte_offset_of_entry >> 1;   // entry i sits at 16 i: plane element i at 8 i
+    return D2{*reinterpret_cast<const double *>(base + half),
+              *reinterpret_cast<const double *>(base + 512 * 8 + half)};
+#else
+    return *reinterpret_cast<const D2 *>(reinterpret_cast<const char *>(tab) + byte_offset_of_entry);
+#endif
+}
+
 MC_HD uint32_t hi32(double x)
 {
     uint64_t b;
@@ -165,7 +180,7 @@ MC_HD double neg2log(double u, const D2 *tab)
     const uint32_t i = (tmp >> 11) & 511u;
     const int32_t k = static_cast<int32_t>(tmp) >> 20;
     const double z = make_double(lo32(u), hx - (tmp & 0xfff00000u));
-    const D2 e = tab[i];
+    const D2 e = table_entry(tab, i << 4);
     const double t = __builtin_fma(z, e.a, 2.0);
     const double w = __builtin_fma(static_cast<double>(k), kM2Ln2, e.b);
     double q = fma_usv(t, 1.0 / 80.0, 1.0 / 32.0);
@@ -235,7 +250,7 @@ MC_HD void sincos_bits(uint32_t z, uint32_t w, const D2 *tab, double &s, double 
     const uint32_t hi = (sw.shr11 & 0xfffu) | 0x43300000u;
 #endif
     const double f = fma_usv(make_double(lo, hi), 0x1p-44, 0x1p-44 - 256.5);
-    const D2 e = *reinterpret_cast<const D2 *>(reinterpret_cast<const char *>(tab) + ((sw.shr11 >> 8) & 0x1ff0u));
+    const D2 e = table_entry(tab, (sw.shr11 >> 8) & 0x1ff0u);
     const double ff = f * f;
     double sp = fma_usv(ff, kSinF5, kSinF3);
     sp = fma_vvs(ff, sp, kSinF1);
@@ -263,7 +278,7 @@ MC_HD double sin_bits_rotated(uint32_t z, uint32_t w, const D2 *rot_tab, double 
     const uint32_t hi = (sw.shr11 & 0xfffu) | 0x43300000u;
 #endif
     const double f = fma_usv(make_double(lo, hi), 0x1p-44, 0x1p-44 - 256.5);
-    const D2 e = *reinterpret_cast<const D2 *>(reinterpret_cast<const char *>(rot_tab) + ((sw.shr11 >> 8) & 0x1ff0u));
+    const D2 e = table_entry(rot_tab, (sw.shr11 >> 8) & 0x1ff0u);
     const double ff = f * f;
     double sp = fma_usv(ff, kSinF5, kSinF3);
     sp = fma_vvs(ff, sp, kSinF1);

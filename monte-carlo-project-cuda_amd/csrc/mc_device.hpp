@@ -133,10 +133,18 @@ struct MathCtx<double> {
         __shared__ f64::D2 s_sincos[MCAMD_TAB_N];
         __shared__ double s_exp_hi[256];
         __shared__ double s_exp_lo[256];
+        static_assert(MCAMD_TAB_N == 512, "f64::table_entry's plane variant assumes 512 entries");
         for (int i = threadIdx.x; i < MCAMD_TAB_N; i += blockDim.x) {
-            s_log[i] = f64::D2{kLogTab[i][0], kLogTab[i][1]};
             const int j = ROTATED ? ((i + MCAMD_TAB_N / 8) & (MCAMD_TAB_N - 1)) : i;
+#if defined(MCAMD_LDS_PLANES)   // experiment: two 8-byte planes per table (fast64.hpp table_entry)
+            reinterpret_cast<double *>(s_log)[i] = kLogTab[i][0];
+            reinterpret_cast<double *>(s_log)[MCAMD_TAB_N + i] = kLogTab[i][1];
+            reinterpret_cast<double *>(s_sincos)[i] = kSinCosTab[j][0];
+            reinterpret_cast<double *>(s_sincos)[MCAMD_TAB_N + i] = kSinCosTab[j][1];
+#else
+            s_log[i] = f64::D2{kLogTab[i][0], kLogTab[i][1]};
             s_sincos[i] = f64::D2{kSinCosTab[j][0], kSinCosTab[j][1]};
+#endif
         }
         for (int i = threadIdx.x; i < 256; i += blockDim.x) {
             s_exp_hi[i] = kExpHiTab[i];
@@ -697,13 +705,18 @@ __device__ __forceinline__ void block_sumN(double (&v)[N])
 // single workgroup — either the last workgroup of the simulation grid to finish (grid_finish: one launch, as the
 // reference) or a separate one-workgroup launch.  Same function, same order, same bits either way.
 // ---------------------------------------------------------------------------------------------
+#ifndef MCAMD_FINISH_ACC   // overridable for the same-box comparison of profiles/r03_finish_acc_ab.txt only
+#define MCAMD_FINISH_ACC 4
+#endif
+static_assert(MCAMD_FINISH_ACC == 1 || MCAMD_FINISH_ACC == 2 || MCAMD_FINISH_ACC == 4 || MCAMD_FINISH_ACC == 8,
+              "the accumulator sets are added pairwise: a power of two");
 // Sums n_records records of N doubles with the BLOCK threads of one workgroup in a fixed order: thread t takes records
 // t, t + BLOCK, ... round-robin into kAcc = 4 independent accumulator sets (more would push the pricing kernels past 80 vector registers, i.e. below six wavefronts per SIMD; four loads in flight per lane hide most of the L2
 // latency of the lone workgroup), the sets are added pairwise, block_sumN finishes.  Result valid in thread 0.
 template <int BLOCK, int N>
 __device__ __forceinline__ void small_final_sum(const double *__restrict__ partials, uint32_t n_records, double (&v)[N])
 {
-    constexpr int kAcc = 4;
+    constexpr int kAcc = MCAMD_FINISH_ACC;
     double s[kAcc][N];
 #pragma unroll
     for (int u = 0; u < kAcc; ++u)

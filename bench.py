@@ -636,6 +636,12 @@ def main(argv=None):
                                 "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic_bytes("store_kernel<float"),
                                 "kernel": "store_kernel<float,false,STEP_MAJOR,vec>",
                                 "algorithmic_bytes_per_launch": bytes_per_launch}
+            if per_gpu % 4 == 0:   # the same store stream with nothing simulated, right after the timed steps: this box's ceiling
+                cs = [ctx.diag_store_pattern(per_gpu, n_steps, capi.F32, traj, payoffs) for _ in range(3)]
+                cms = sum(cs) / len(cs)
+                line["roofline"]["same_run_ceiling"] = {"kernel_ms": cms, "launches": len(cs),
+                                                        "GB_per_s": (per_gpu * n_steps * 4 + per_gpu * 4) / (cms / 1e3) / 1e9}
+                line["roofline"]["frac_of_same_run_store_ceiling"] = cms / (avg_kernel_s * 1e3)
         elif wl in ("european252", "european252_f32"):
             f64 = prec == capi.F64
             line["roofline"] = valu_roofline(W, stale, "price_f64" if f64 else "price_f32",

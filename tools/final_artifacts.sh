@@ -3,7 +3,7 @@
 # written under gpurun_out/$TAG/ (copied into profiles/ by hand afterwards, see profiles/README.md).
 #   tools/final_artifacts.sh TAG
 set -uo pipefail
-TAG="${1:-r02}"
+TAG="${1:-r03}"
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 O="$R/gpurun_out/$TAG"
 mkdir -p "$O"
@@ -19,5 +19,10 @@ run bench_european252 python3 bench.py --gpus 1 --steps 20 --warmup 5 \
  && run bench_nmc_european_window python3 bench.py --workload nmc --nmc-window european --steps 1 --warmup 0 --no-cpu-baseline \
  && run bench_config5_1gpu python3 bench.py --global-paths 1000000000 --steps 3 --warmup 1 --no-cpu-baseline --no-store-roofline --no-sweep --no-accuracy --no-nmc \
  && run bench_2rank_gloo_one_gpu python3 bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --no-cpu-baseline \
+ && run bench_nmc_fused python3 bench.py --workload nmc --nmc-strategy fused --steps 3 --warmup 1 --no-cpu-baseline \
  && run nmc_strategies python3 tools/nmc_strategies.py \
- && { timeout -k 10 300 tools/clock_probe 10000000 252 2.5 sweep > "$O/clock_probe.jsonl" 2> "$O/clock_probe.err"; echo "clock_probe rc=$?"; }
+ && run form_ab python3 tools/form_ab.py \
+ && run fold_ab python3 tools/fold_ab.py \
+ && run nmc_form_ab python3 tools/nmc_form_ab.py \
+ && run fuzz_nmc python3 tools/fuzz_nmc.py --seconds 60 --seed 41 \
+ && run fuzz_window_price python3 tools/fuzz_window_price.py --seconds 60 --seed 42

@@ -1,3 +1,9 @@
+#!/usr/bin/env bash
+# Runs on the GPU box (through gpurun): same-box A/B of the shipped library against the LDS-planes variant
+# (-DMCAMD_LDS_PLANES), timing (tools/ab_lib.py, alternating worker processes) and one PMC pass per library over
+# the same worker.  Build the variant first, in the build container:
+#   python3 -c "import importlib; importlib.import_module('monte-carlo-project-cuda_amd.build').build_variant('lds_planes', ['-DMCAMD_LDS_PLANES'])"
+# Result: profiles/r03_lds_planes_ab.txt
 set -uo pipefail
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 O="$R/gpurun_out/r03_lds"

@@ -41,6 +41,16 @@ def test_slot_counts_describe_the_built_library(lib):
         counts = json.load(f)
     assert capi.build_id() == bmod.build_id() == counts["build_id"]
     assert 50 < counts["price_f64"] < 120 and 20 < counts["price_f32"] < 40
+    # the fixed yardstick of bench.py (W_FLOOR) is a floor: never above the shipped loops' counts,
+    # and the default loops are the cheaper ones
+    from importlib import util as ilu
+    spec = ilu.spec_from_file_location("bench_for_floor", os.path.join(ROOT, "bench.py"))
+    bench = ilu.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for key, floor in bench.W_FLOOR.items():
+        assert floor <= counts[key] <= 1.1 * floor, (key, floor, counts[key])
+        assert counts[key] < counts[key + "_product"]
+    assert counts["nmc_wave_f64_window"] < counts["nmc_wave_f64_window_product"]
 
 
 def test_struct_layout_is_the_documented_abi():

@@ -77,3 +77,53 @@ def test_sharded_price_equals_single_process(world, oracle):
         assert math.isclose(price, fin["price"], rel_tol=1e-12) and math.isclose(se, fin["std_err"], rel_tol=1e-9)
     # every rank holds the same reduced result
     assert len({(g[1], g[2], g[3]) for g in got}) == 1
+
+
+def _nmc_worker(rank, world, port, n_paths, n_steps, n_inner, q):
+    """Nested MC sharded by outer path, as bench.py --workload nmc does it on N ranks: each rank prices the points of its
+    outer paths (here: the oracle's brute-force point pricer with the SHIFTED point id) and ONE all-reduce of the
+    statistics record {sum, sum of squares, points, work, live} gives every rank the whole job's diagnostic."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    pkg_ = importlib.import_module("monte-carlo-project-cuda_amd")
+    from oracle import pyoracle as o
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, m = pkg_.sharding.shard_range(n_paths, world, rank)
+    po = o.make_params(B=104.0, P1=1, P2=5, use_window=1, n_paths=n_paths, n_steps=n_steps, seed=1234)
+    outer = o.mc_paths(po, 64, lo, m, want_traj=True, want_counts=True)
+    pi = o.make_params(B=104.0, P1=1, P2=5, use_window=1, n_paths=n_paths, n_steps=n_steps, n_paths_inner=n_inner, seed=1235)
+    prices = [o.nmc_point(pi, 64, (lo + q_) * n_steps + s_, s_, float(outer["traj"][s_, q_]), int(outer["counts"][s_, q_]))
+              for q_ in range(m) for s_ in range(n_steps)]
+    rec = [sum(prices), sum(p * p for p in prices), len(prices), 64.0 * len(prices), float(len(prices))]
+    s, s2, n, work, live = pkg_.sharding.allreduce_vector(rec)
+    fin = pkg_.capi.finalize_nmc_stats([s, s2, work / 64.0, live, 0.0, n])
+    q.put((rank, fin.sum, fin.n, fin.price, fin.work_steps, fin.live_steps, prices))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_nested_mc_equals_single_process(oracle):
+    import torch.multiprocessing as mp
+    world, n_paths, n_steps, n_inner = 2, 5, 4, 30
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nmc_worker, args=(r, world, port, n_paths, n_steps, n_inner, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the whole job on one process: same streams (global path ids), so the shards' points are the whole job's points
+    po = oracle.make_params(B=104.0, P1=1, P2=5, use_window=1, n_paths=n_paths, n_steps=n_steps, seed=1234)
+    outer = oracle.mc_paths(po, 64, 0, n_paths, want_traj=True, want_counts=True)
+    pi = oracle.make_params(B=104.0, P1=1, P2=5, use_window=1, n_paths=n_paths, n_steps=n_steps, n_paths_inner=n_inner, seed=1235)
+    whole = [oracle.nmc_point(pi, 64, q_ * n_steps + s_, s_, float(outer["traj"][s_, q_]), int(outer["counts"][s_, q_]))
+             for q_ in range(n_paths) for s_ in range(n_steps)]
+    assert got[0][6] + got[1][6] == whole and max(whole) > 0
+    for _, s, n, mean, work, live, _ in got:
+        assert n == n_paths * n_steps and math.isclose(s, math.fsum(whole), rel_tol=1e-12)
+        assert math.isclose(mean, math.fsum(whole) / n, rel_tol=1e-12) and work == 64.0 * n and live == n

@@ -495,9 +495,57 @@ __device__ __forceinline__ uint32_t window_open_lanes(int32_t count, int32_t cou
 
 // EARLY: leave the loop when the window has closed for the whole wavefront (off when the caller needs the
 // terminal price itself, i.e. for the S_T control variate).
-// PAIRSUM (window-less log-space paths of the pricing kernel only): add up Box-Muller pair sums (PairSum) instead of
-// single normals; the caller's MathCtx must then hold the rotated sin/cos table (MathCtx::init<true>).
-template <typename T, bool WINDOW, bool LOGSPACE, bool ANTI, bool EARLY = WINDOW, bool PAIRSUM = false>
+// The window-less log-space path of the pricing kernel: only the sum of a path's normals matters (PairSum).  A thread
+// walks NP paths with consecutive subsequences at once, block by block — NP independent chains in one loop body (two
+// chains run 1.6-3.2 % faster than one on one box, three and four slower: profiles/r03_pairsum_paths_ab.txt) — and
+// acc[p] = (z_1 + ... + z_n) / kUnit of path p.  The kernel's MathCtx must hold the ROTATED sin/cos table
+// (MathCtx::init<true>).
+#ifndef MCAMD_PAIRSUM_PATHS   // overridable for that same-box comparison only
+#define MCAMD_PAIRSUM_PATHS 2
+#endif
+constexpr int kPairSumPaths = MCAMD_PAIRSUM_PATHS;
+static_assert(kPairSumPaths >= 1 && kPairSumPaths <= 4, "MCAMD_PAIRSUM_PATHS must be in [1, 4]");
+template <typename T, int NP>
+__device__ __forceinline__ void pair_sums_of_paths(const MathCtx<T> &m, const PhiloxKeys &seed, uint64_t subsequence0,
+                                                   uint32_t n_sim, T (&acc)[NP])
+{
+    constexpr int NB = Normals<T>::kPerBlock;
+    const uint32_t n_full = n_sim / NB;
+    const uint32_t rem = n_sim - n_full * NB;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = T(0);
+    for (uint32_t k = 0; k < n_full; ++k) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc[p] = PairSum<T>::add_block(acc[p], m, seed, subsequence0 + p, k);
+    }
+    if (rem) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc[p] += PairSum<T>::head(m, seed, subsequence0 + p, n_full, rem);
+    }
+}
+
+// What a window-less path contributes, from its pair-sum total: ln(S_T / S_in) = n drift + (vol kUnit) acc.
+template <typename T, bool ANTI>
+__device__ __forceinline__ Sample<T> sample_from_pair_sum(const StepConsts<T> &c, const MathCtx<T> &m, T acc, T S_in,
+                                                          uint32_t n_sim)
+{
+    const T nd = c.drift * static_cast<T>(n_sim);
+    const T vol_unit = c.vol * PairSum<T>::kUnit;
+    const T St = exp_of_logreturn(S_in, fma_t(acc, vol_unit, nd), m);
+    Sample<T> out;
+    out.steps_run = n_sim;
+    out.live_steps = 0;
+    out.pay = payoff<T, false>(St, 0, c);
+    out.ctrl = St;
+    if (ANTI) {
+        const T St2 = exp_of_logreturn(S_in, fma_t(-acc, vol_unit, nd), m);
+        out.pay = T(0.5) * (out.pay + payoff<T, false>(St2, 0, c));
+        out.ctrl = T(0.5) * (St + St2);
+    }
+    return out;
+}
+
+template <typename T, bool WINDOW, bool LOGSPACE, bool ANTI, bool EARLY = WINDOW>
 __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, const MathCtx<T> &m, const PhiloxKeys &seed,
                                                      uint64_t subsequence, T St, int32_t count, uint32_t n_sim,
                                                      T log_start = T(0))
@@ -512,15 +560,9 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
     // lanes entering the next block with an open window (EARLY only; every active lane at the start)
     uint32_t open_lanes = EARLY ? static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(true))) : 0u;
     uint64_t live_steps = 0;   // up to 64 x n_sim
-    // LOGSPACE: ln(St / S_ref) so far in exponent units (PAIRSUM: the sum of the normals so far / kUnit; the twin's is its negative)
+    // LOGSPACE: ln(St / S_ref) so far in exponent units
     T acc = WINDOW ? log_start : T(0), acc2 = acc;
-    static_assert(!PAIRSUM || (LOGSPACE && !WINDOW), "pair sums serve window-less log-space paths only");
-    if constexpr (PAIRSUM) {
-        // window-less path in log space: only the sum of the path's normals matters (PairSum); acc is that sum in
-        // units of PairSum<T>::kUnit.
-        for (uint32_t k = 0; k < n_full; ++k) acc = PairSum<T>::add_block(acc, m, seed, subsequence, k);
-        if (rem) acc += PairSum<T>::head(m, seed, subsequence, n_full, rem);
-    } else if (LOGSPACE) {
+    if (LOGSPACE) {
         // ln(St / S_ref) carried in the exponent's units: acc += x with x = drift + vol G the step's exponent (the
         // same Exponents the product form multiplies by; the twin's is 2 drift - x).  The barrier test B > St is
         // ln(B / S_start) > acc.
@@ -593,14 +635,7 @@ __device__ __forceinline__ Sample<T> simulate_sample(const StepConsts<T> &c, con
         St = ps.value(m);
         if (ANTI) St2 = ps2.value(m);
     }
-    if constexpr (PAIRSUM) {
-        // acc = (z_1 + ... + z_n) / kUnit: ln(S_T / S_in) = n drift + (vol kUnit) acc
-        const T nd = c.drift * static_cast<T>(n_sim);
-        const T vol_unit = c.vol * PairSum<T>::kUnit;
-        const T S_in = St;
-        St = exp_of_logreturn(S_in, fma_t(acc, vol_unit, nd), m);
-        if (ANTI) St2 = exp_of_logreturn(S_in, fma_t(-acc, vol_unit, nd), m);
-    } else if (LOGSPACE) {
+    if (LOGSPACE) {
         // acc = ln(St / S_ref) in exponent units; S_ref = c.S_start with a window (acc started at log_start), else the
         // start price itself (acc started at 0)
         const T S_ref = WINDOW ? c.S_start : St;

@@ -52,9 +52,7 @@ __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *_
     double acc[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = 0.0;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_local; i += stride) {
-        const Sample<T> smp = simulate_sample<T, WINDOW, LOGSPACE, ANTI, WINDOW && !CV, PAIRSUM>(
-            c, m, key, a.path_offset + i, c.S_start, c.Ik, c.n_sim);
+    auto add_sample = [&](const Sample<T> &smp) {
         const double y = static_cast<double>(smp.pay);
         acc[0] += y;
         acc[1] = __builtin_fma(y, y, acc[1]);
@@ -64,6 +62,22 @@ __global__ __launch_bounds__(kBlock) void price_kernel(PriceArgs<T> a, double *_
             acc[3] = __builtin_fma(cc, cc, acc[3]);
             acc[4] = __builtin_fma(y, cc, acc[4]);
         }
+    };
+    if constexpr (PAIRSUM) {
+        // a thread owns kPairSumPaths consecutive paths and walks them together (mc_device.hpp pair_sums_of_paths);
+        // the job's last thread may own fewer
+        constexpr int NP = kPairSumPaths;
+        for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; g * NP < a.n_local; g += stride) {
+            T sums[NP];
+            pair_sums_of_paths<T, NP>(m, key, a.path_offset + g * NP, c.n_sim, sums);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                if (g * NP + p < a.n_local) add_sample(sample_from_pair_sum<T, ANTI>(c, m, sums[p], c.S_start, c.n_sim));
+        }
+    } else {
+        for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_local; i += stride)
+            add_sample(simulate_sample<T, WINDOW, LOGSPACE, ANTI, WINDOW && !CV>(c, m, key, a.path_offset + i, c.S_start,
+                                                                               c.Ik, c.n_sim));
     }
     block_sumN<kBlock, N>(acc);
     grid_finish<kBlock, N>(acc, partials, a.fin);

@@ -295,8 +295,9 @@ def test_in_kernel_finish_equals_the_separate_reduction_bit_for_bit(ctx):
     torch.cuda.synchronize()
     assert many[:, 0].tolist() == want
     # a grid one workgroup past the limit takes the separate 1024-thread reduction, whatever the flag says
-    big = ctx.price_paths(opt, capi.make_sim(8193 * 256, 32, capi.F32, seed=3))
-    big2 = ctx.price_paths(opt, capi.make_sim(8193 * 256, 32, capi.F32, seed=3, flags=capi.FLAG_SEPARATE_REDUCE))
+    # (the window-less loop walks two paths per thread: 512 paths per workgroup)
+    big = ctx.price_paths(opt, capi.make_sim(8193 * 512, 32, capi.F32, seed=3))
+    big2 = ctx.price_paths(opt, capi.make_sim(8193 * 512, 32, capi.F32, seed=3, flags=capi.FLAG_SEPARATE_REDUCE))
     assert big.grid == 8193 and big.sum == big2.sum and big.total_ms >= big.kernel_ms
     del x
 

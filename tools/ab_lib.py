@@ -10,6 +10,7 @@ JOBS = [("price f64 1M x 252", dict(n=1_000_000, prec=64, window=0)),
         ("price f32 1M x 252", dict(n=1_000_000, prec=32, window=0)),
         ("price f64 10M x 252", dict(n=10_000_000, prec=64, window=0)),
         ("price f64 100M x 252", dict(n=100_000_000, prec=64, window=0)),
+        ("price f32 10M x 252", dict(n=10_000_000, prec=32, window=0)),
         ("bullet f64 1M x 252 (one path per thread)", dict(n=1_000_000, prec=64, window=1))]
 
 

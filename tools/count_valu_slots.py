@@ -154,9 +154,10 @@ KERNELS = {
     # key: (source, mangled kernel, path-steps advanced per loop iteration)
     # window-less in-register pricing: the default loop sums the log-returns (LOGSPACE = true); the product form
     # (MCAMD_FLAG_PRODUCT_FORM) multiplies the running price every step
-    "price_f64": ("price_f64.hip", "_ZN5mcamd12price_kernelIdLb0ELb1ELi0EEE", 2),
+    # (the pair-sum loop walks kPairSumPaths = 2 paths per thread: 2 x 2 / 2 x 4 path-steps per iteration)
+    "price_f64": ("price_f64.hip", "_ZN5mcamd12price_kernelIdLb0ELb1ELi0EEE", 4),
     "price_f64_product": ("price_f64.hip", "_ZN5mcamd12price_kernelIdLb0ELb0ELi0EEE", 2),
-    "price_f32": ("price_f32.hip", "_ZN5mcamd12price_kernelIfLb0ELb1ELi0EEE", 4),
+    "price_f32": ("price_f32.hip", "_ZN5mcamd12price_kernelIfLb0ELb1ELi0EEE", 8),
     "price_f32_product": ("price_f32.hip", "_ZN5mcamd12price_kernelIfLb0ELb0ELi0EEE", 4),
     "store_f32": ("store.hip", "_ZN5mcamd12store_kernelIfLb0ELi0ELb1EEE", 16),
     # nested MC inner stage, fp64, barrier window (BASELINE configs[3]): St is evaluated at every step for the count

@@ -24,10 +24,14 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for f in glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True):
+    # gpurun merges every call's output into the same scratch directory: a directory profiled twice holds two runs.
+    # Only the newest file of each pass is digested (one run of the command per pass).
+    newest = lambda pattern: sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)[-1:]
+    for f in newest(os.path.join(src, "trace", "**", "*_kernel_stats.csv")):
         shutil.copy(f, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
     agg = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
+    passes = sorted(d for d in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d))
+    for f in [x for d in passes for x in newest(os.path.join(d, "**", "*_counter_collection.csv"))]:
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))

@@ -99,6 +99,11 @@ def test_bench_emits_one_json_line_with_roofline_and_cpu_baseline():
     dev = d["device"]
     assert dev["arch"].startswith("gfx950") and dev["compute_units"] >= 200 and dev["hbm_free_gb"] > 100
     assert rl["valu_slots_per_path_step"] and "stale" not in rl     # the slot count describes the loaded library
+    # the fixed yardstick (operation floor of the scheme) and the PMC-derived VALU occupancy ride along
+    assert rl["valu_slots_floor"] <= rl["valu_slots_per_path_step"] and 0.2 < rl["frac_vs_floor"] <= rl["frac"]
+    assert "valu_busy" in rl and (rl["valu_busy"] is None or "value" in rl["valu_busy"])
+    if rl["valu_busy"] and rl["valu_busy"]["value"] is not None:    # digest taken from this very library
+        assert 0.5 < rl["valu_busy"]["value"] < 1.1
     assert d["cfg1"]["closed_form"]["evals"] == 1_000_000 and d["cfg1"]["serial_mc_port_f64"]["paths"] == 1_000_000
 
 
@@ -136,3 +141,17 @@ def test_two_ranks_sharing_the_card_reproduce_the_one_rank_job(workload, strateg
     else:
         assert abs(two["price"] - one["price"]) <= 1e-12 * one["price"]
         assert abs(two["std_err"] - one["std_err"]) <= 1e-9 * one["std_err"]
+
+
+@pytest.mark.gpu
+def test_store_workload_line_carries_its_same_run_ceiling():
+    """`--workload store` (BASELINE configs[2]'s kernel at a small path count): the HBM roofline object names the bytes,
+    and beside it the pure-store pass of the same shape measured in the same process."""
+    d = _bench_line(["--workload", "store", "--paths", "4000000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    rl = d["roofline"]
+    assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and rl["peak"] == 8000.0 and d["dtype"] == "f32"
+    assert rl["algorithmic_bytes_per_launch"] >= 4_000_000 * 252 * 4 + 4_000_000 * 4
+    assert 0.05 < rl["frac"] < 1.05
+    c = rl["same_run_ceiling"]
+    assert c["kernel_ms"] > 0 and c["GB_per_s"] > 500 and 0.3 < rl["frac_of_same_run_store_ceiling"] < 1.3
+    assert abs(d["price"] - 13.2697) < 0.2

@@ -95,3 +95,16 @@ def test_multi_gpu_cpp_host_runs_on_the_visible_devices(built):
     m = re.search(r"devices (\d+) .* price ([0-9.]+) \+- ([0-9.]+) .*closed form ([0-9.]+)", out.stdout)
     assert m, out.stdout
     assert int(m.group(1)) >= 1 and abs(float(m.group(2)) - float(m.group(4))) < 4.5 * float(m.group(3))
+    # the nested-MC host on the same group: per-device buffers, mcamd_group_nmc_fused; the mean of all point prices must be
+    # the single-context call's (same seeds, same global path ids)
+    n = re.search(r"nested MC on (\d+) device\(s\): (\d+) points x 200 inner paths, mean point price ([0-9.]+), lane efficiency ([0-9.]+)", out.stdout)
+    assert n, out.stdout
+    assert int(n.group(2)) == 4096 * 100 and 0.3 < float(n.group(4)) <= 1.0
+    import torch
+    capi = pkg.capi
+    with capi.Context(0) as ctx:
+        opt = capi.make_option(B=120.0, P1=10, P2=50, use_window=1)
+        t, c, o = (torch.empty(4096 * 100, dtype=d, device="cuda") for d in (torch.float64, torch.int32, torch.float64))
+        torch.cuda.synchronize()
+        want = ctx.nmc_fused(opt, capi.make_sim(4096, 100, capi.F64, seed=1235, n_paths_inner=200), 1234, t, c, o)
+    assert math.isclose(float(n.group(3)), want.price, rel_tol=1e-10)

@@ -1,8 +1,9 @@
 // clock_probe.hip — DIAGNOSTIC build of the in-register pricing loop with cycle stamps around it.
 //
 // Answers "at what clock does the chip run the fp64 (or fp32) step loop?" (MI355X_MICROARCH.md, DVFS
-// give-back item 6): the body of price_kernel (csrc/price_impl.hpp — the same simulate_sample, the same
-// launch shape) is stamped once before and once after the path loop with s_memtime (shader cycles) and
+// give-back item 6): the body of price_kernel (csrc/price_impl.hpp — the same loops, the same launch shapes: the
+// default pair-sum loop with two paths per thread, PAIRSUM = true, or the product form, simulate_sample) is stamped
+// once before and once after the path loop with s_memtime (shader cycles) and
 // s_memrealtime (100 MHz), by lane 0 of every wave; in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz,
 // median over waves, read from the last launch after >= 2 s of back-to-back launches.  Stamps go to a buffer
 // of their own; no output value depends on them.  The shipped library contains no stamp.
@@ -32,7 +33,7 @@ using namespace mcamd;
         }                                                                                   \
     } while (0)
 
-template <typename T>
+template <typename T, bool PAIRSUM>
 __global__ __launch_bounds__(kBlock) void probe_kernel(PriceArgs<T> a, double *__restrict__ partials,
                                                        uint64_t *__restrict__ stamps)
 {
@@ -40,18 +41,29 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(PriceArgs<T> a, double *_
     extern __shared__ char occupancy_pad[];
     if (threadIdx.x == 1023) occupancy_pad[0] = 0;   // never true for 256-thread blocks: keeps the symbol referenced
     const uint64_t w_entry = __builtin_amdgcn_s_memrealtime();   // kernel entry, before the LDS tables are filled
-    const MathCtx<T> m = MathCtx<T>::init();
+    const MathCtx<T> m = MathCtx<T>::template init<PAIRSUM>();
     const PhiloxKeys key = PhiloxKeys::make(a.seed);
     const StepConsts<T> c = resident(a.c);
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     double acc[2] = {0.0, 0.0};
-    const uint64_t t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_local; i += stride) {
-        const Sample<T> smp =
-            simulate_sample<T, false, false, false>(c, m, key, a.path_offset + i, c.S_start, c.Ik, c.n_sim);
+    auto add = [&](const Sample<T> &smp) {
         const double y = static_cast<double>(smp.pay);
         acc[0] += y;
         acc[1] = __builtin_fma(y, y, acc[1]);
+    };
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+    if constexpr (PAIRSUM) {
+        constexpr int NP = kPairSumPaths;
+        for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; g * NP < a.n_local; g += stride) {
+            T sums[NP];
+            pair_sums_of_paths<T, NP>(m, key, a.path_offset + g * NP, c.n_sim, sums);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                if (g * NP + p < a.n_local) add(sample_from_pair_sum<T, false>(c, m, sums[p], c.S_start, c.n_sim));
+        }
+    } else {
+        for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n_local; i += stride)
+            add(simulate_sample<T, false, false, false>(c, m, key, a.path_offset + i, c.S_start, c.Ik, c.n_sim));
     }
     // the payoff must be complete before the closing stamp: make the stamp depend on it
     const uint32_t done = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(__double2hiint(acc[0])));
@@ -71,9 +83,10 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(PriceArgs<T> a, double *_
     }
 }
 
-template <typename T>
+template <typename T, bool PAIRSUM = true>
 static int run(const char *name, uint64_t n_paths, uint32_t n_steps, double seconds, uint32_t pad_bytes = 0)
 {
+    constexpr uint64_t kPathsPerThread = PAIRSUM ? kPairSumPaths : 1;
     PathJob j{};
     const double dt = 1.0 / n_steps, r = 0.1, v = 0.2;
     j.drift = (r - 0.5 * v * v) * dt;
@@ -86,8 +99,8 @@ static int run(const char *name, uint64_t n_paths, uint32_t n_steps, double seco
     j.seed = 1234;
     j.n_local = n_paths;
     j.precision = sizeof(T) * 8;
-    PriceArgs<T> a{make_consts<T>(j), j.seed, 0, j.n_local, 0.0};
-    const uint32_t grid = static_cast<uint32_t>((n_paths + kBlock - 1) / kBlock);
+    PriceArgs<T> a{make_consts<T>(j), j.seed, 0, j.n_local, 0.0, GridFinish{nullptr, nullptr, -1.0}};
+    const uint32_t grid = static_cast<uint32_t>(((n_paths + kPathsPerThread - 1) / kPathsPerThread + kBlock - 1) / kBlock);
     const uint64_t n_waves = static_cast<uint64_t>(grid) * (kBlock / 64);
     double *d_part = nullptr;
     uint64_t *d_st = nullptr;
@@ -104,7 +117,7 @@ static int run(const char *name, uint64_t n_paths, uint32_t n_steps, double seco
     while (true) {
         a.seed = 1234 + launches;
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(probe_kernel<T>, dim3(grid), dim3(kBlock), pad_bytes, 0, a, d_part, d_st);
+        hipLaunchKernelGGL((probe_kernel<T, PAIRSUM>), dim3(grid), dim3(kBlock), pad_bytes, 0, a, d_part, d_st);
         CK(hipEventRecord(e1, 0));
         ++launches;
         if (launches % 8 == 0) {
@@ -163,11 +176,12 @@ static int run(const char *name, uint64_t n_paths, uint32_t n_steps, double seco
     for (uint32_t b = 0; b < grid; ++b) sum += part[2 * b];
     std::printf("{\"probe\": \"%s\", \"lds_pad_bytes\": %u, \"paths\": %llu, \"steps\": %u, \"launches\": %d, \"kernel_ms_median\": %.4f, "
                 "\"span_ms_last_launch\": %.4f, \"in_kernel_clock_ghz_median\": %.4f, \"clock_ghz_p05\": %.4f, "
-                "\"clock_ghz_p95\": %.4f, \"wave_lifetime_cycles_median\": %.0f, \"path_steps_per_wave_iteration\": %d, "
+                "\"clock_ghz_p95\": %.4f, \"wave_lifetime_cycles_median\": %.0f, \"paths_per_thread\": %d, \"path_steps_per_wave_iteration\": %d, "
                 "\"simd_cycles_per_wave_iteration\": %.1f, \"waves_in_loop_per_simd\": [%.2f, %.2f, %.2f], "
                 "\"us_before_loop_median\": %.2f, \"us_before_loop_p95\": %.2f, \"price\": %.6f}\n",
                 name, pad_bytes, static_cast<unsigned long long>(n_paths), n_steps, launches, kernel_ms, span_ms, clk,
-                ghz[n_waves / 20], ghz[n_waves - 1 - n_waves / 20], cyc[n_waves / 2], Normals<T>::kPerBlock,
+                ghz[n_waves / 20], ghz[n_waves - 1 - n_waves / 20], cyc[n_waves / 2], static_cast<int>(kPathsPerThread),
+                static_cast<int>(kPathsPerThread) * Normals<T>::kPerBlock,
                 cyc_per_wave_iter, resident[0], resident[1], resident[2], pre_ticks[n_waves / 2] * 0.01,
                 pre_ticks[n_waves - 1 - n_waves / 20] * 0.01, std::exp(-0.1) * sum / static_cast<double>(n_paths));
     CK(hipFree(d_part));
@@ -180,15 +194,17 @@ int main(int argc, char **argv)
     const uint64_t n_paths = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 10000000ull;
     const uint32_t n_steps = argc > 2 ? static_cast<uint32_t>(std::atoi(argv[2])) : 252u;
     const double seconds = argc > 3 ? std::atof(argv[3]) : 2.5;
-    if (run<double>("price_f64", n_paths, n_steps, seconds)) return 1;
-    if (run<float>("price_f32", n_paths, n_steps, seconds)) return 1;
+    if (run<double, true>("price_f64 (default: pair sums, log space)", n_paths, n_steps, seconds)) return 1;
+    if (run<float, true>("price_f32 (default: pair sums, log space)", n_paths, n_steps, seconds)) return 1;
+    if (run<double, false>("price_f64_product", n_paths, n_steps, seconds)) return 1;
+    if (run<float, false>("price_f32_product", n_paths, n_steps, seconds)) return 1;
     if (argc > 4) {   // occupancy sweep: pad the workgroup's LDS so that fewer workgroups (= waves per SIMD) fit a CU
-        // fp64: 20.5 KB of tables per workgroup -> 7 per CU unpadded; 40 KB -> 4; 53 KB -> 3; 80 KB -> 2; 159 KB -> 1
-        for (uint32_t pad : {12u << 10, 20u << 10, 33u << 10, 60u << 10, 139u << 10})
-            if (run<double>("price_f64_occupancy", n_paths, n_steps, 0.6, pad)) return 1;
+        // fp64 default loop: 106 VGPRs -> 4 workgroups per CU unpadded; LDS pads cap it further: 53 KB -> 3; 80 KB -> 2; 159 KB -> 1
+        for (uint32_t pad : {33u << 10, 60u << 10, 139u << 10})
+            if (run<double, true>("price_f64_occupancy", n_paths, n_steps, 0.6, pad)) return 1;
         // fp32: no tables -> 8 per CU unpadded
         for (uint32_t pad : {0u, 26u << 10, 39u << 10, 53u << 10, 80u << 10, 159u << 10})
-            if (run<float>("price_f32_occupancy", n_paths, n_steps, 0.4, pad)) return 1;
+            if (run<float, true>("price_f32_occupancy", n_paths, n_steps, 0.4, pad)) return 1;
     }
     return 0;
 }

@@ -27,7 +27,7 @@ tables:           ## regenerate the fp64 math tables (needs mpmath)
 
 HIPCC ?= hipcc
 PROBE_FLAGS = --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Imonte-carlo-project-cuda_amd/csrc
-PROBES = clock_probe init_probe store_variants ubench_bank ubench_valu ubench_hbm_write naive_port_baseline
+PROBES = clock_probe init_probe store_variants ubench_bank ubench_valu ubench_hbm_write naive_port_baseline launch_overhead
 
 probes: $(addprefix tools/,$(PROBES))   ## the diagnostic binaries behind profiles/ (run them on an MI355X)
 

@@ -14,8 +14,8 @@
  *    mcamd_last_error() returns the calling thread's last message;
  *  - "d_" pointers are device (HBM) pointers on the context's device, owned by the caller;
  *  - calls are synchronous on the context's stream (as the reference's wrappers are:
- *    cudaDeviceSynchronize at inc/wrappers.cuh:48,79,115,157,233,297); a context is not
- *    thread-safe, distinct contexts are independent;
+ *    cudaDeviceSynchronize at inc/wrappers.cuh:48,79,115,157,233,297) unless named *_enqueue; a
+ *    context is not thread-safe, distinct contexts are independent;
  *  - option parameters travel in the structs passed to each call; there is no global
  *    __constant__ symbol to upload first (reference: hello.cu:22, inc/trajectories.cuh:12);
  *  - random numbers: counter-based Philox4x32-10 held in registers, key = seed,
@@ -24,7 +24,10 @@
  *    block).  There is no RNG state array and no setup kernel (replaces setup_kernel,
  *    inc/tool.cuh:192-195, and init_rng_kernel, inc/testing.cuh:95-98).  Results therefore
  *    do not depend on how paths are sharded over GPUs, blocks or threads;
- *  - payoff sums are accumulated in fp64 whatever the path precision.
+ *  - payoff sums are accumulated in fp64 whatever the path precision;
+ *  - the in-register kernels carry ln(St/S0) through the step loop and exponentiate where the price is
+ *    needed; MCAMD_FLAG_PRODUCT_FORM asks for the reference's recurrence St *= exp(...) as written
+ *    (same draws, same scheme, ~1e-14 relative apart in fp64).
  */
 #ifndef MCAMD_H
 #define MCAMD_H
@@ -146,7 +149,8 @@ typedef struct mcamd_result {
     double ci_lo;      /* price -/+ 1.96 std_err */
     double ci_hi;
     float kernel_ms;   /* HIP-event time of the simulation kernel alone, on the context's stream */
-    float total_ms;    /* HIP-event time of the whole call's device work (kernel + final reduce + D2H) */
+    float total_ms;    /* HIP-event time of the whole call's device work (kernel + final reduce + D2H; equal to kernel_ms
+                          when the kernel finishes its own sum: MCAMD_FLAG_SEPARATE_REDUCE) */
     uint32_t grid;     /* launch shape the engine chose (threadsPerBlock / number_of_blocks of the */
     uint32_t block;    /* reference wrappers are accepted by the shim and ignored) */
     /* control variate (MCAMD_FLAG_CONTROL_VARIATE), zero otherwise: c = S_T - E[S_T] per sample */
@@ -205,13 +209,16 @@ int mcamd_memcpy_to_device(mcamd_ctx *ctx, void *d_dst, const void *h_src, uint6
  *   wrapper_gpu_bullet_option[_atomic]  inc/wrappers.cuh:59-125  (use_window = 1)
  *     simulateBulletOptionPriceMultipleBlockGPU[atomic]  inc/trajectories.cuh:115-271
  * and is the multi-step European pricer of BASELINE configs 2 and 5 (use_window = 0).
- * The library picks the kernel: window jobs of millions of paths (plain estimator) run the lane-compacting kernel, the
- * rest one path per thread; a path's payoff does not depend on which (same Philox stream, same arithmetic), so any
- * sharding of a job gives the same sums up to fp64 summation order. */
+ * The library picks the kernel: window jobs of millions of paths (plain estimator) run the lane-compacting kernel, other
+ * window jobs one path per thread, window-less jobs the pair-sum loop (two paths per thread: ln(S_T/S_0) from the sum of
+ * the path's normals, a Box-Muller pair contributing sqrt2 r sin(a + pi/4)); a path's payoff does not depend on which
+ * (same Philox stream, same arithmetic), so any sharding of a job gives the same sums up to fp64 summation order.
+ * Jobs of up to 8192 workgroups are ONE launch: the kernel's last workgroup sums the block records in a fixed order
+ * (see MCAMD_FLAG_SEPARATE_REDUCE). */
 int mcamd_price_paths(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, mcamd_result *res);
 
-/* Asynchronous form of mcamd_price_paths: enqueues the simulation kernel and the final reduction on the context's
- * stream and returns without waiting.  d_stats (device, >= 6 doubles) receives {sum, sumsq, sum_c, sum_cc, sum_yc, n}
+/* Asynchronous form of mcamd_price_paths: enqueues the simulation kernel (and, for large grids, the final reduction) on
+ * the context's stream and returns without waiting.  d_stats (device, >= 6 doubles) receives {sum, sumsq, sum_c, sum_cc, sum_yc, n}
  * (the cross sums are zero without MCAMD_FLAG_CONTROL_VARIATE).  The caller orders later work on the same stream —
  * typically ONE all-reduce of d_stats over the ranks — and finalizes after synchronising (mcamd_finalize_stats), so
  * a multi-step driver pays no host round trip per step.  New (the reference is fully synchronous). */
@@ -283,9 +290,10 @@ int mcamd_reduce_partials(mcamd_ctx *ctx, const void *d_in, uint64_t n, int prec
 int mcamd_nmc_inner(mcamd_ctx *ctx, const mcamd_option *opt, const mcamd_sim *sim, int layout, int variant,
                     const void *d_prices, const int32_t *d_counts, void *d_point_prices, mcamd_result *res);
 
-/* Nested Monte Carlo, outer + inner stage fused in ONE launch: every workgroup simulates and stores the outer
- * paths it owns (seed = outer_seed), then prices exactly those points (inner seed = sim->seed).  d_prices /
- * d_counts / d_point_prices are OUTPUTS here (same shapes and layout rule as above; d_counts may be NULL for
+/* Nested Monte Carlo, outer + inner stage fused in ONE launch: the wavefronts of a persistent grid first simulate and
+ * store the outer paths, 64 at a time from a device-scope queue (seed = outer_seed), publish them (release / acquire
+ * across the device's L2s), then price the points exactly as mcamd_nmc_inner(MCAMD_NMC_WAVE_PER_POINT) does (inner
+ * seed = sim->seed).  d_prices / d_counts / d_point_prices are OUTPUTS here (same shapes and layout rule as above; d_counts may be NULL for
  * use_window = 0).  Results are bit-identical to mcamd_simulate_trajectories + mcamd_nmc_inner with the same
  * two seeds.  Replaces compute_nmc_one_block_per_point_with_outter, inc/nmc.cuh:113-275
  * (wrapper_gpu_bullet_option_nmc_one_kernel, inc/wrappers.cuh:209-266). */

@@ -52,7 +52,9 @@ PEAK_HBM_GBS = 8000.0
 # instruction is removed — these do not move with the implementation, so paths/s x W_FLOOR / peak only rises when the
 # kernel gets faster.  Window-less European path-step: Philox4x32-10 (17 multiplies + 17 three-input xors per block that
 # no hoisting removes) + the uniforms + -2 ln u + sqrt + ONE sine per Box-Muller pair + one accumulate.
-W_FLOOR = {"price_f64": 62.5, "price_f32": 22.25}
+# Window loop of the nested-MC inner stage (fp64): the same Philox and uniforms, -2 ln u, the volatility-scaled radius,
+# sine AND cosine (each step needs its own exponent), and per step one add, one compare and one count update.
+W_FLOOR = {"price_f64": 62.5, "price_f32": 22.25, "nmc_wave_f64_window": 72.5}
 
 METRIC = "MC paths/sec, European call (price error vs closed-form BS reported)"
 

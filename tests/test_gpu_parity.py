@@ -1163,6 +1163,23 @@ def test_full_size_config4_reference_bullet_window(ctx, oracle):
     # 100 steps; here 252 steps — compare with the engine's own outer estimate instead)
     direct = ctx.price_paths(opt, capi.make_sim(4_000_000, n_steps, capi.F64, seed=99))
     assert abs(V[0].mean().item() - direct.price) < 5 * (direct.std_err + 10.0 / math.sqrt(n_paths * n_inner) + 8.0 / math.sqrt(n_paths))
+    # (5) the job as an 8-GPU run shards it (by outer path, 8192 paths per rank): ranks 0, 3 and 7 priced on
+    # this one card, each through its own outer store + inner stage with path_offset = 8192 g, reproduce the whole
+    # job's columns BIT FOR BIT (stored prices, counts, point prices) and their statistics add up accordingly
+    m = n_paths // 8
+    for g in (0, 3, 7):
+        lo = g * m
+        so = capi.make_sim(n_paths, n_steps, capi.F64, seed=1234, path_offset=lo, n_paths_local=m)
+        si = capi.make_sim(n_paths, n_steps, capi.F64, seed=1235, path_offset=lo, n_paths_local=m, n_paths_inner=n_inner)
+        ts, cs, os_ = dev(m * n_steps, torch.float64), dev(m * n_steps, torch.int32), dev(m * n_steps, torch.float64)
+        ctx.simulate_trajectories(opt, so, ts, cs)
+        rs = ctx.nmc_inner(opt, si, ts, cs, os_)
+        assert torch.equal(ts.view(n_steps, m), S[:, lo:lo + m]) and torch.equal(cs.view(n_steps, m), C[:, lo:lo + m])
+        assert torch.equal(os_.view(n_steps, m), V[:, lo:lo + m]), g
+        assert rs.n == m * n_steps and math.isclose(rs.sum, V[:, lo:lo + m].sum().item(), rel_tol=1e-10)
+        tf, cf, of = dev(m * n_steps, torch.float64), dev(m * n_steps, torch.int32), dev(m * n_steps, torch.float64)
+        ctx.nmc_fused(opt, si, 1234, tf, cf, of)
+        assert torch.equal(of, os_) and torch.equal(tf, ts)
 
 
 def test_accuracy_252_variance_reduced_estimator_scales_to_1e_minus_4(ctx):

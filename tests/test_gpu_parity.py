@@ -1242,7 +1242,16 @@ def test_full_size_config3_properties(ctx):
         sd = 100 * math.exp(0.1 * t) * math.sqrt(math.exp(0.04 * t) - 1)
         assert abs(m - 100 * math.exp(0.1 * t)) < 5 * sd / math.sqrt(n) + 1e-3
     assert torch.isfinite(rows[::50]).all()
-    del traj
+    # the job as an 8-GPU run shards it ("shards the [step][path] buffer by path columns per GPU; no
+    # exchange"): rank 5's columns, stored through path_offset = 5 n / 8 into a buffer of their own, are the whole job's
+    # columns bit for bit, payoffs and statistics included
+    m_, lo = n // 8, 5 * (n // 8)
+    part, ppay = dev(m_ * steps, torch.float32), dev(m_, torch.float32)
+    sp = ctx.simulate_trajectories(opt, capi.make_sim(n, steps, capi.F32, seed=1234, path_offset=lo, n_paths_local=m_), part, None, ppay)
+    assert torch.equal(part.view(steps, m_), rows[:, lo:lo + m_])
+    assert torch.equal(ppay, torch.clamp(rows[-1, lo:lo + m_] - 100.0, min=0.0))
+    assert sp.n == m_ and math.isclose(sp.sum, ppay.double().sum().item(), rel_tol=1e-12)
+    del traj, part, ppay
     torch.cuda.empty_cache()
 
 
@@ -1250,7 +1259,7 @@ def test_full_size_config3_properties(ctx):
 def test_differential_fuzzers_stay_clean(tool, seconds):
     # a few seconds of the differential fuzzers of tools/ (compacting kernels against the non-compacting ones; thousands
     # of random jobs), on a fixed seed (a test must not change from day to day); the long runs are in
-    # profiles/r02_fuzz_*.json
+    # profiles/r03_fuzz_*.json
     seed = 20261005
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", tool), "--seconds", str(seconds), "--seed", str(seed)],
